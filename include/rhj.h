@@ -1,0 +1,162 @@
+/*
+ * rhj.h -- C-ABI of librhj_hip.so: the MI355X (gfx950) radix hash join engine.
+ *
+ * This is the drop-in boundary for the hot path of pelekoudasq/radixHashJoin,
+ *     void Result::multiRadixHashJoin(JobScheduler&, relation&, relation&)   (Result.h:30, Result.cpp:90-124)
+ * and for the job bodies it fans out (HistogramJob / PartitionJob / JoinJob, JobScheduler.cpp:149-192).
+ * Plain pointers and sizes only; no HIP, torch or C++ types.  Every entry point cites the reference
+ * interface it replaces.  The reference-side binding is shown in INTEGRATION.md; the C++ host mirror
+ * of the reference surface that calls this ABI lives in radixhashjoin_amd/host/.
+ *
+ * Conventions
+ *   - all functions return RHJ_OK (0) or a negative rhj_status; rhj_last_error(ctx) has the text.
+ *   - "d_" arguments are DEVICE pointers (HBM), everything else is host memory.
+ *   - a context owns one HIP stream and a grow-only HBM workspace.  A context is NOT thread-safe:
+ *     create one per calling thread, exactly like each query thread of the reference owns a
+ *     private JobScheduler (MainScheduler.cpp:6-14).  Different contexts may run concurrently.
+ *   - all arithmetic is 64-bit unsigned integer; pair ORDER in outputs is unspecified (SURVEY §8a:
+ *     no consumer of Result observes it); the pair MULTISET is bit-exact with the reference.
+ */
+#ifndef RHJ_H
+#define RHJ_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RHJ_ABI_VERSION 1
+
+/* layout-identical to `struct tuple` (structs.h:33-36): key = rowID, payload = join value */
+typedef struct { uint64_t key; uint64_t payload; } rhj_tuple;
+/* layout-identical to `struct key_tuple` (Result.h:9-12) */
+typedef struct { uint64_t keyR; uint64_t keyS; } rhj_pair;
+
+typedef struct rhj_ctx rhj_ctx;
+
+typedef enum {
+    RHJ_OK = 0,
+    RHJ_E_INVALID = -1,    /* bad argument */
+    RHJ_E_NODEVICE = -2,   /* no usable HIP device */
+    RHJ_E_HIP = -3,        /* a HIP call failed (rhj_last_error has hipGetErrorString) */
+    RHJ_E_NOMEM = -4,      /* HBM or host allocation failed */
+    RHJ_E_OVERFLOW = -5    /* d_out too small: *out_count holds the exact size needed, pairs beyond capacity dropped */
+} rhj_status;
+
+/* Radix plan.  The reference hard-codes one 8-bit pass (HASH_LSB, Result.cpp:5,91); here the
+ * number of passes and bits per pass are run-time knobs.  0/0 with passes=-1 = automatic:
+ * no partitioning when the smaller input fits one LDS hash table, else the fewest bits such
+ * that the average build partition fits one LDS table, split over at most two passes. */
+typedef struct {
+    int32_t passes;        /* -1 auto, 0, 1 or 2 */
+    int32_t bits1;         /* radix bits of pass 1 (LSBs [0,bits1)), 1..11; 0 = auto */
+    int32_t bits2;         /* radix bits of pass 2 (bits [bits1,bits1+bits2)), 1..11; 0 = auto */
+    int32_t probe_split;   /* max probe tuples per join task (skew/load balance); 0 = auto */
+} rhj_opts;
+
+/* per-kernel device time of the LAST rhj_join / rhj_join_dev / stage call, from HIP events on the
+ * context's stream (only filled while profiling is enabled, see rhj_set_profiling). */
+typedef enum {
+    RHJ_K_HIST = 0,        /* radix histogram           (HistogramJob::run) */
+    RHJ_K_SCAN = 1,        /* prefix sums               (PartitionJob::run prefix + structs.cpp:168-173) */
+    RHJ_K_SCATTER = 2,     /* scatter-partition         (PartitionJob::run scatter + structs.cpp:183-194) */
+    RHJ_K_TASKS = 3,       /* join task list            (the JoinJob scheduling loop, Result.cpp:98-107) */
+    RHJ_K_JOIN = 4,        /* bucket build+probe+write  (JoinJob::run / Result::join_buckets / add_result) */
+    RHJ_K_AUX = 5,         /* unit tables, memsets, checksum, generators */
+    RHJ_K_COUNT = 6
+} rhj_kernel_kind;
+
+typedef struct {
+    double   ms[RHJ_K_COUNT];        /* summed device ms per kind */
+    uint32_t launches[RHJ_K_COUNT];  /* launches per kind */
+    double   total_ms;               /* first launch start -> last launch end */
+    int32_t  passes, bits1, bits2;   /* the plan that ran */
+    uint64_t ntasks;                 /* join tasks executed */
+} rhj_timings;
+
+/* ---- lifetime: replaces JobScheduler::init / stop / destroy for the join path
+ *      (JobScheduler.cpp:67-86, 140-146, 89-97) --------------------------------------------- */
+int  rhj_abi_version(void);
+int  rhj_device_count(void);
+int  rhj_init(int device, rhj_ctx **out_ctx);
+void rhj_destroy(rhj_ctx *ctx);
+const char *rhj_last_error(const rhj_ctx *ctx);          /* ctx may be NULL: last global error */
+/* run on a caller-owned hipStream_t (e.g. torch's current stream); NULL = context's own stream */
+int  rhj_set_stream(rhj_ctx *ctx, void *hip_stream);
+int  rhj_set_profiling(rhj_ctx *ctx, int enabled);
+int  rhj_get_timings(rhj_ctx *ctx, rhj_timings *out);
+int  rhj_sync(rhj_ctx *ctx);                             /* JobScheduler::barrier (JobScheduler.cpp:103-122) */
+/* pre-size / release the HBM workspace (otherwise grown on demand) */
+int  rhj_reserve(rhj_ctx *ctx, uint64_t nR, uint64_t nS, const rhj_opts *opts);
+int  rhj_release_workspace(rhj_ctx *ctx);
+void rhj_default_opts(rhj_opts *opts);
+/* the plan rhj_join* would use for these sizes (host logic only, no device needed; ctx may be NULL) */
+int  rhj_plan(uint64_t nR, uint64_t nS, const rhj_opts *in, rhj_opts *resolved);
+
+/* ---- the drop-in: replaces the body of Result::multiRadixHashJoin (Result.cpp:90-124) ----
+ * Host AoS in, one result page out.  *out_page is NULL when there is no match (Result::isEmpty,
+ * Result.cpp:16-18) else a malloc() block laid out like one reference result page
+ * (Result.cpp:21-35): 8 bytes `next` pointer (= NULL) followed by *out_count rhj_pair.
+ * The caller owns it and releases it with free() (as ~Result does, Result.cpp:127-133).
+ * Inputs are neither modified nor retained. */
+int rhj_join(rhj_ctx *ctx, const rhj_tuple *R, uint64_t nR, const rhj_tuple *S, uint64_t nS,
+             const rhj_opts *opts, void **out_page, uint64_t *out_count);
+
+/* ---- device-resident variant (inputs/outputs already in HBM).  d_out may be NULL with
+ * out_capacity 0 to count only.  Returns RHJ_E_OVERFLOW (and the exact *out_count) when
+ * out_capacity is too small; call again with a larger buffer. */
+int rhj_join_dev(rhj_ctx *ctx, const rhj_tuple *d_R, uint64_t nR, const rhj_tuple *d_S, uint64_t nS,
+                 const rhj_opts *opts, rhj_pair *d_out, uint64_t out_capacity, uint64_t *out_count);
+
+/* ---- stage entry points (device pointers), one per reference job body ---------------------
+ * rhj_histogram: HistogramJob::run over the whole relation + the reduction of structs.cpp:168-173:
+ *   d_hist[b] = #{ i : ((payload_i >> shift) & (2^bits-1)) == b },  d_hist has 2^bits uint64. */
+int rhj_histogram(rhj_ctx *ctx, const rhj_tuple *d_rel, uint64_t n, int shift, int bits, uint64_t *d_hist);
+/* rhj_prefix: the exclusive prefix of PartitionJob::run (JobScheduler.cpp:163-169):
+ *   d_start[0]=0, d_start[b+1]=d_start[b]+d_hist[b]; d_start has nbins+1 uint64. */
+int rhj_prefix(rhj_ctx *ctx, const uint64_t *d_hist, uint64_t nbins, uint64_t *d_start);
+/* rhj_partition: relation_info::hash_relation (structs.cpp:144-204) generalised to one or two passes:
+ *   d_out = tuples of d_in grouped by partition id  p = payload & (2^(bits1+bits2)-1)  laid out in the
+ *   order  (p & (2^bits1-1)) * 2^bits2 + (p >> bits1)   [pass-1 digit major, pass-2 digit minor; with
+ *   bits2 == 0 this is the reference's bucket order];  d_part_start[k], k in [0, 2^(bits1+bits2)], are
+ *   the partition boundaries in that order.  Order of tuples INSIDE a partition is unspecified. */
+int rhj_partition(rhj_ctx *ctx, const rhj_tuple *d_in, uint64_t n, int bits1, int bits2,
+                  rhj_tuple *d_out, uint64_t *d_part_start);
+/* rhj_bucket_join: the JoinJob loop of Result.cpp:98-107 + JoinJob::run + Result::join_buckets +
+ *   add_result: for every partition k with both sides non-empty, build an LDS hash table on the smaller
+ *   side (S when |R_k| >= |S_k|, JobScheduler.cpp:187) and probe with the other; emit (rowR,rowS).
+ *   radix_bits = number of low payload bits that are constant inside a partition (0 if unpartitioned). */
+int rhj_bucket_join(rhj_ctx *ctx, const rhj_tuple *d_Rp, const uint64_t *d_startR,
+                    const rhj_tuple *d_Sp, const uint64_t *d_startS, uint64_t nparts, int radix_bits,
+                    int probe_split, rhj_pair *d_out, uint64_t out_capacity, uint64_t *out_count);
+
+/* ---- utilities -------------------------------------------------------------------------- */
+/* order-insensitive checksum of SURVEY.md App. A over a device pair array:
+ *   sum over pairs of mix(keyR * 0x100000001B3 ^ mix(keyS))  (mod 2^64), mix = splitmix64 step */
+int rhj_pairs_checksum_dev(rhj_ctx *ctx, const rhj_pair *d_pairs, uint64_t n, uint64_t *checksum);
+/* synthetic inputs generated in HBM:  kind 0: R[i] = {i+row0, mix(1 + (i+row0) % D)}
+ *   kind 1: uniform FK, counter based: S[j] = {j+row0, mix(1 + mix((j+row0) ^ seed) % D)}
+ *   kind 2: Zipf(theta) FK: rank r in [1,D] by inverse-CDF of the continuous approximation from
+ *           u = mix((j+row0) ^ seed) / 2^64; payload = mix(r)            (theta given as theta_milli/1000)
+ *   kind 3: disjoint: S[j] = {j+row0, mix(D + 1 + j + row0)}
+ *   kind 4: constant: T[i] = {i+row0, D} */
+int rhj_generate_dev(rhj_ctx *ctx, int kind, rhj_tuple *d_out, uint64_t n, uint64_t row0, uint64_t D,
+                     uint64_t seed, int theta_milli);
+/* closed-form expectation for PK/FK inputs (R of kind 0 with D == |R| global, unique payloads):
+ *   every S tuple {j, mix(k)} matches exactly R row k-1: *count = n, *checksum = sum mix((k-1)*0x100000001B3 ^ mix(j)).
+ *   Computed by one streaming pass over S that inverts mix(); does not run the join. */
+int rhj_expected_pkfk_dev(rhj_ctx *ctx, const rhj_tuple *d_S, uint64_t n, uint64_t *count, uint64_t *checksum);
+
+/* raw HBM helpers so a plain C/C++ host (no HIP headers) can use the device-resident API */
+int rhj_dev_alloc(rhj_ctx *ctx, uint64_t bytes, void **d_ptr);
+int rhj_dev_free(rhj_ctx *ctx, void *d_ptr);
+int rhj_copy_h2d(rhj_ctx *ctx, void *d_dst, const void *src, uint64_t bytes);
+int rhj_copy_d2h(rhj_ctx *ctx, void *dst, const void *d_src, uint64_t bytes);
+int rhj_dev_mem_info(rhj_ctx *ctx, uint64_t *free_bytes, uint64_t *total_bytes);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RHJ_H */

@@ -1,0 +1,275 @@
+"""ctypes binding of include/rhj.h (librhj_hip.so).  No compute happens in Python."""
+import ctypes as C
+import os
+
+import numpy as np
+
+TUPLE = np.dtype([("key", "<u8"), ("payload", "<u8")])   # rhj_tuple == reference `tuple` (structs.h:33-36)
+PAIR = np.dtype([("keyR", "<u8"), ("keyS", "<u8")])      # rhj_pair  == reference `key_tuple` (Result.h:9-12)
+
+RHJ_OK, RHJ_E_INVALID, RHJ_E_NODEVICE, RHJ_E_HIP, RHJ_E_NOMEM, RHJ_E_OVERFLOW = 0, -1, -2, -3, -4, -5
+KERNEL_KINDS = ("hist", "scan", "scatter", "tasks", "join", "aux")
+
+_vp, _u64, _i32 = C.c_void_p, C.c_uint64, C.c_int32
+
+
+class Opts(C.Structure):
+    """rhj_opts: passes=-1 auto; bits per pass; probe_split = max probe tuples per join task."""
+    _fields_ = [("passes", _i32), ("bits1", _i32), ("bits2", _i32), ("probe_split", _i32)]
+
+    def __init__(self, passes=-1, bits1=0, bits2=0, probe_split=0):
+        super().__init__(passes, bits1, bits2, probe_split)
+
+    def __repr__(self):
+        return f"Opts(passes={self.passes}, bits1={self.bits1}, bits2={self.bits2}, probe_split={self.probe_split})"
+
+
+class Timings(C.Structure):
+    _fields_ = [("ms", C.c_double * 6), ("launches", C.c_uint32 * 6), ("total_ms", C.c_double),
+                ("passes", _i32), ("bits1", _i32), ("bits2", _i32), ("ntasks", _u64)]
+
+    def as_dict(self):
+        d = {k: {"ms": self.ms[i], "launches": self.launches[i]} for i, k in enumerate(KERNEL_KINDS)}
+        d.update(total_ms=self.total_ms, passes=self.passes, bits1=self.bits1, bits2=self.bits2, ntasks=self.ntasks)
+        return d
+
+
+class RhjError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__(f"rhj error {code}: {msg}")
+        self.code = code
+
+
+def lib_path():
+    return os.path.join(os.path.dirname(os.path.abspath(__file__)), "librhj_hip.so")
+
+
+_LIB = None
+
+# every symbol include/rhj.h declares: name -> (restype, argtypes)
+_P = C.POINTER
+SYMBOLS = {
+    "rhj_abi_version": (C.c_int, []),
+    "rhj_device_count": (C.c_int, []),
+    "rhj_init": (C.c_int, [C.c_int, _P(_vp)]),
+    "rhj_destroy": (None, [_vp]),
+    "rhj_last_error": (C.c_char_p, [_vp]),
+    "rhj_set_stream": (C.c_int, [_vp, _vp]),
+    "rhj_set_profiling": (C.c_int, [_vp, C.c_int]),
+    "rhj_get_timings": (C.c_int, [_vp, _P(Timings)]),
+    "rhj_sync": (C.c_int, [_vp]),
+    "rhj_reserve": (C.c_int, [_vp, _u64, _u64, _P(Opts)]),
+    "rhj_release_workspace": (C.c_int, [_vp]),
+    "rhj_default_opts": (None, [_P(Opts)]),
+    "rhj_plan": (C.c_int, [_u64, _u64, _P(Opts), _P(Opts)]),
+    "rhj_join": (C.c_int, [_vp, _vp, _u64, _vp, _u64, _P(Opts), _P(_vp), _P(_u64)]),
+    "rhj_join_dev": (C.c_int, [_vp, _vp, _u64, _vp, _u64, _P(Opts), _vp, _u64, _P(_u64)]),
+    "rhj_histogram": (C.c_int, [_vp, _vp, _u64, C.c_int, C.c_int, _vp]),
+    "rhj_prefix": (C.c_int, [_vp, _vp, _u64, _vp]),
+    "rhj_partition": (C.c_int, [_vp, _vp, _u64, C.c_int, C.c_int, _vp, _vp]),
+    "rhj_bucket_join": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _u64, C.c_int, C.c_int, _vp, _u64, _P(_u64)]),
+    "rhj_pairs_checksum_dev": (C.c_int, [_vp, _vp, _u64, _P(_u64)]),
+    "rhj_generate_dev": (C.c_int, [_vp, C.c_int, _vp, _u64, _u64, _u64, _u64, C.c_int]),
+    "rhj_expected_pkfk_dev": (C.c_int, [_vp, _vp, _u64, _P(_u64), _P(_u64)]),
+    "rhj_dev_alloc": (C.c_int, [_vp, _u64, _P(_vp)]),
+    "rhj_dev_free": (C.c_int, [_vp, _vp]),
+    "rhj_copy_h2d": (C.c_int, [_vp, _vp, _vp, _u64]),
+    "rhj_copy_d2h": (C.c_int, [_vp, _vp, _vp, _u64]),
+    "rhj_dev_mem_info": (C.c_int, [_vp, _P(_u64), _P(_u64)]),
+}
+
+
+def load_library():
+    """Load librhj_hip.so and declare every prototype.  Raises if the library is not built."""
+    global _LIB
+    if _LIB is None:
+        path = lib_path()
+        if not os.path.exists(path):
+            raise ImportError(f"{path} is missing: build it with `make -C radixhashjoin_amd/csrc` "
+                              f"(or __graft_entry__.build()); there is no CPU fallback")
+        lib = C.CDLL(path)
+        for name, (res, args) in SYMBOLS.items():
+            fn = getattr(lib, name)         # AttributeError if the ABI lost a symbol
+            fn.restype = res
+            fn.argtypes = args
+        _LIB = lib
+    return _LIB
+
+
+def plan(nR, nS, opts=None):
+    """Resolved radix plan for these sizes (host logic only, works without a GPU)."""
+    lib = load_library()
+    out = Opts()
+    rc = lib.rhj_plan(nR, nS, C.byref(opts) if opts is not None else None, C.byref(out))
+    if rc != RHJ_OK:
+        raise RhjError(rc, "bad options")
+    return out
+
+
+def _addr(x):
+    """device address of: int, DeviceBuffer, or anything with data_ptr() (torch tensor)"""
+    if x is None:
+        return None
+    if isinstance(x, int):
+        return x
+    if isinstance(x, DeviceBuffer):
+        return x.ptr
+    if hasattr(x, "data_ptr"):
+        return x.data_ptr()
+    raise TypeError(f"not a device pointer: {type(x)}")
+
+
+class DeviceBuffer:
+    """A raw HBM allocation owned through the C-ABI (rhj_dev_alloc / rhj_dev_free)."""
+
+    def __init__(self, engine, nbytes):
+        self.engine = engine
+        self.nbytes = int(nbytes)
+        p = _vp()
+        engine._chk(engine.lib.rhj_dev_alloc(engine.ctx, self.nbytes, C.byref(p)))
+        self.ptr = p.value
+
+    @classmethod
+    def from_numpy(cls, engine, arr):
+        arr = np.ascontiguousarray(arr)
+        b = cls(engine, max(arr.nbytes, 16))
+        if arr.nbytes:
+            engine._chk(engine.lib.rhj_copy_h2d(engine.ctx, b.ptr, arr.ctypes.data, arr.nbytes))
+        return b
+
+    def to_numpy(self, dtype, count):
+        out = np.empty(count, dtype=dtype)
+        if out.nbytes:
+            self.engine._chk(self.engine.lib.rhj_copy_d2h(self.engine.ctx, out.ctypes.data, self.ptr, out.nbytes))
+        return out
+
+    def free(self):
+        if self.ptr:
+            self.engine.lib.rhj_dev_free(self.engine.ctx, self.ptr)
+            self.ptr = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
+class Engine:
+    """One rhj_ctx: a HIP stream + HBM workspace on one GPU.  Not thread-safe (one per caller thread)."""
+
+    def __init__(self, device=0):
+        self.lib = load_library()
+        self.ctx = None
+        c = _vp()
+        rc = self.lib.rhj_init(device, C.byref(c))
+        if rc != RHJ_OK:
+            raise RhjError(rc, (self.lib.rhj_last_error(None) or b"").decode())
+        self.ctx = c
+
+    def close(self):
+        if self.ctx:
+            self.lib.rhj_destroy(self.ctx)
+            self.ctx = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _chk(self, rc, allow=()):
+        if rc != RHJ_OK and rc not in allow:
+            raise RhjError(rc, (self.lib.rhj_last_error(self.ctx) or b"").decode())
+        return rc
+
+    # ---- context ------------------------------------------------------------------------------
+    def set_stream(self, raw_stream):
+        self._chk(self.lib.rhj_set_stream(self.ctx, raw_stream))
+
+    def set_profiling(self, on=True):
+        self._chk(self.lib.rhj_set_profiling(self.ctx, 1 if on else 0))
+
+    def timings(self):
+        t = Timings()
+        self._chk(self.lib.rhj_get_timings(self.ctx, C.byref(t)))
+        return t.as_dict()
+
+    def sync(self):
+        self._chk(self.lib.rhj_sync(self.ctx))
+
+    def reserve(self, nR, nS, opts=None):
+        self._chk(self.lib.rhj_reserve(self.ctx, nR, nS, C.byref(opts) if opts is not None else None))
+
+    def release_workspace(self):
+        self._chk(self.lib.rhj_release_workspace(self.ctx))
+
+    def mem_info(self):
+        f, t = _u64(), _u64()
+        self._chk(self.lib.rhj_dev_mem_info(self.ctx, C.byref(f), C.byref(t)))
+        return f.value, t.value
+
+    def alloc(self, nbytes):
+        return DeviceBuffer(self, nbytes)
+
+    def to_device(self, arr):
+        return DeviceBuffer.from_numpy(self, arr)
+
+    # ---- the drop-in (host arrays) -----------------------------------------------------------
+    def join(self, R, S, opts=None):
+        """rhj_join: host AoS in -> numpy array of (rowR,rowS) pairs (copied out of the result page)."""
+        R = np.ascontiguousarray(R, dtype=TUPLE)
+        S = np.ascontiguousarray(S, dtype=TUPLE)
+        page, n = _vp(), _u64()
+        self._chk(self.lib.rhj_join(self.ctx, R.ctypes.data, len(R), S.ctypes.data, len(S),
+                                    C.byref(opts) if opts is not None else None, C.byref(page), C.byref(n)))
+        out = np.empty(n.value, dtype=PAIR)
+        if page.value:
+            head = C.c_uint64.from_address(page.value).value       # bucket_info::next must be NULL
+            assert head == 0
+            C.memmove(out.ctypes.data, page.value + 8, out.nbytes)
+            C.CDLL(None).free(_vp(page.value))
+        else:
+            assert n.value == 0
+        return out
+
+    # ---- device-resident ------------------------------------------------------------------------
+    def join_dev(self, d_R, nR, d_S, nS, d_out=None, capacity=0, opts=None, allow_overflow=False):
+        n = _u64()
+        rc = self.lib.rhj_join_dev(self.ctx, _addr(d_R), nR, _addr(d_S), nS,
+                                   C.byref(opts) if opts is not None else None, _addr(d_out), capacity, C.byref(n))
+        self._chk(rc, allow=(RHJ_E_OVERFLOW,) if allow_overflow else ())
+        return n.value
+
+    def histogram(self, d_rel, n, shift, bits, d_hist):
+        self._chk(self.lib.rhj_histogram(self.ctx, _addr(d_rel), n, shift, bits, _addr(d_hist)))
+
+    def prefix(self, d_hist, nbins, d_start):
+        self._chk(self.lib.rhj_prefix(self.ctx, _addr(d_hist), nbins, _addr(d_start)))
+
+    def partition(self, d_in, n, bits1, bits2, d_out, d_part_start):
+        self._chk(self.lib.rhj_partition(self.ctx, _addr(d_in), n, bits1, bits2, _addr(d_out), _addr(d_part_start)))
+
+    def bucket_join(self, d_Rp, d_startR, d_Sp, d_startS, nparts, radix_bits, d_out=None, capacity=0,
+                    probe_split=0, allow_overflow=False):
+        n = _u64()
+        rc = self.lib.rhj_bucket_join(self.ctx, _addr(d_Rp), _addr(d_startR), _addr(d_Sp), _addr(d_startS), nparts,
+                                      radix_bits, probe_split, _addr(d_out), capacity, C.byref(n))
+        self._chk(rc, allow=(RHJ_E_OVERFLOW,) if allow_overflow else ())
+        return n.value
+
+    def pairs_checksum(self, d_pairs, n):
+        c = _u64()
+        self._chk(self.lib.rhj_pairs_checksum_dev(self.ctx, _addr(d_pairs), n, C.byref(c)))
+        return c.value
+
+    def generate(self, kind, d_out, n, row0=0, D=1, seed=0, theta_milli=0):
+        self._chk(self.lib.rhj_generate_dev(self.ctx, kind, _addr(d_out), n, row0, D, seed, theta_milli))
+
+    def expected_pkfk(self, d_S, n):
+        cnt, c = _u64(), _u64()
+        self._chk(self.lib.rhj_expected_pkfk_dev(self.ctx, _addr(d_S), n, C.byref(cnt), C.byref(c)))
+        return cnt.value, c.value
+
+
+GEN_R, GEN_S_UNIFORM, GEN_S_ZIPF, GEN_S_DISJOINT, GEN_CONST = 0, 1, 2, 3, 4

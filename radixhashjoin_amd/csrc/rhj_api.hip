@@ -1,0 +1,702 @@
+// rhj_api.hip -- the C-ABI of include/rhj.h: context, HBM workspace, radix plan, orchestration.
+// Host orchestration replaces the JobScheduler dispatch of the join path: what the reference does
+// with 5 barriers and <= 288 heap Job objects per join is a fixed sequence of
+// asynchronous kernel launches on one HIP stream with a single host sync for the result count.
+#include "../../include/rhj.h"
+#include "rhj_internal.h"
+
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+namespace {
+
+thread_local std::string g_last_error;
+
+struct DevBuf {
+    void *p = nullptr;
+    size_t cap = 0;
+};
+
+struct Prof {
+    bool on = false;
+    std::vector<hipEvent_t> pool;          // event pairs, reused
+    std::vector<int> kinds;                // kind per recorded pair
+    size_t used = 0;
+};
+
+}  // namespace
+
+struct rhj_ctx {
+    int device = 0;
+    hipStream_t own_stream = nullptr;
+    hipStream_t stream = nullptr;
+    std::string err;
+    Prof prof;
+    rhj_timings last{};
+    // workspace (grow-only)
+    DevBuf in_R, in_S;                 // H2D staging of host inputs (rhj_join)
+    DevBuf part_R, part_S, part_tmp;   // partitioned relations, pass-1 intermediate
+    DevBuf ps_R, ps_S, ps_1;           // partition boundaries (final R, final S, pass-1 scratch)
+    DevBuf seg0, unit_start, unit_hist, unit_base;
+    DevBuf tasks, counters;            // counters: [0] u64 out_count, [1] u32 ntasks (+pad), [2] u64 checksum
+    DevBuf out_pairs;                  // rhj_join's device result buffer
+    DevBuf hist_tmp;
+    // state of the last partition phase (consumed by join_phase)
+    const void *cur_R = nullptr, *cur_S = nullptr;
+    const u64 *cur_psR = nullptr, *cur_psS = nullptr;
+    u64 cur_nparts = 0, cur_nR = 0, cur_nS = 0;
+    int cur_radix_bits = 0;
+    u32 cur_probe_split = 0;
+};
+
+namespace {
+
+int fail(rhj_ctx *ctx, int code, const std::string &msg)
+{
+    g_last_error = msg;
+    if (ctx) ctx->err = msg;
+    return code;
+}
+
+#define HIPCHK(ctx, call)                                                                          \
+    do {                                                                                           \
+        hipError_t e_ = (call);                                                                    \
+        if (e_ != hipSuccess)                                                                      \
+            return fail(ctx, e_ == hipErrorOutOfMemory ? RHJ_E_NOMEM : RHJ_E_HIP,                  \
+                        std::string(#call) + ": " + hipGetErrorString(e_));                        \
+    } while (0)
+
+#define RHJCHK(call)                                                                               \
+    do {                                                                                           \
+        int r_ = (call);                                                                           \
+        if (r_ != RHJ_OK) return r_;                                                               \
+    } while (0)
+
+int ensure(rhj_ctx *ctx, DevBuf &b, size_t bytes)
+{
+    if (bytes <= b.cap) return RHJ_OK;
+    if (b.p) { HIPCHK(ctx, hipFree(b.p)); b.p = nullptr; b.cap = 0; }
+    // round up to 2 MiB so that repeated slightly-larger requests do not re-allocate every time
+    size_t want = (bytes + ((size_t)2 << 20) - 1) & ~(((size_t)2 << 20) - 1);
+    hipError_t e = hipMalloc(&b.p, want);
+    if (e != hipSuccess) {
+        b.p = nullptr;
+        (void)hipGetLastError();
+        return fail(ctx, RHJ_E_NOMEM, "hipMalloc(" + std::to_string(want) + " B): " + hipGetErrorString(e));
+    }
+    b.cap = want;
+    return RHJ_OK;
+}
+
+void release(DevBuf &b)
+{
+    if (b.p) (void)hipFree(b.p);
+    b.p = nullptr;
+    b.cap = 0;
+}
+
+int use_device(rhj_ctx *ctx)
+{
+    if (!ctx) return fail(nullptr, RHJ_E_INVALID, "null context");
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    return RHJ_OK;
+}
+
+// ---- profiling: one event pair per launch, resolved lazily -------------------------------------
+struct Span {
+    rhj_ctx *c;
+    Span(rhj_ctx *ctx, int kind) : c(ctx)
+    {
+        if (!c->prof.on) return;
+        Prof &p = c->prof;
+        if (p.used * 2 + 2 > p.pool.size()) {
+            hipEvent_t a, b;
+            if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) { p.on = false; return; }
+            p.pool.push_back(a);
+            p.pool.push_back(b);
+        }
+        p.kinds.push_back(kind);
+        (void)hipEventRecord(p.pool[p.used * 2], c->stream);
+    }
+    ~Span()
+    {
+        if (!c->prof.on) return;
+        Prof &p = c->prof;
+        (void)hipEventRecord(p.pool[p.used * 2 + 1], c->stream);
+        p.used++;
+    }
+};
+
+void prof_reset(rhj_ctx *ctx)
+{
+    ctx->prof.used = 0;
+    ctx->prof.kinds.clear();
+    memset(&ctx->last, 0, sizeof(ctx->last));
+}
+
+int check_launch(rhj_ctx *ctx, const char *what)
+{
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(ctx, RHJ_E_HIP, std::string(what) + " launch: " + hipGetErrorString(e));
+    return RHJ_OK;
+}
+
+int ilog2_ceil(u64 x)
+{
+    int b = 0;
+    while (((u64)1 << b) < x) b++;
+    return b;
+}
+
+// ---- radix plan (host logic) --------------------------------------------------------------------
+// Reference: one fixed 8-bit pass (Result.cpp:5,91).  Here: the fewest radix bits such that the
+// average build-side partition fills at most 3/4 of one LDS hash table, in <= 2 passes.
+int resolve_plan(u64 nR, u64 nS, const rhj_opts *in, rhj_opts *out)
+{
+    rhj_opts o;
+    if (in) o = *in; else rhj_default_opts(&o);
+    const u64 nb = nR < nS ? nR : nS;
+    const u64 fit = (u64)JOIN_CHUNK * JOIN_FILL_NUM / JOIN_FILL_DEN;
+    if (o.passes < -1 || o.passes > 2 || o.bits1 < 0 || o.bits2 < 0 || o.bits1 > PART_MAX_BITS ||
+        o.bits2 > PART_MAX_BITS || o.probe_split < 0)
+        return RHJ_E_INVALID;
+    if (o.passes == -1) {
+        if (o.bits1 > 0) o.passes = o.bits2 > 0 ? 2 : 1;
+        else {
+            int bits = 0;
+            if (nb > (u64)JOIN_CHUNK) bits = ilog2_ceil((nb + fit - 1) / fit);
+            if (bits == 0) o.passes = 0;
+            else if (bits <= 8) { o.passes = 1; o.bits1 = bits; }
+            else {
+                if (bits > 2 * PART_MAX_BITS) bits = 2 * PART_MAX_BITS;
+                o.passes = 2; o.bits1 = (bits + 1) / 2; o.bits2 = bits / 2;
+            }
+        }
+    }
+    if (o.passes == 0) { o.bits1 = 0; o.bits2 = 0; }
+    if (o.passes == 1) { if (o.bits1 == 0) o.bits1 = 8; o.bits2 = 0; }
+    if (o.passes == 2) { if (o.bits1 == 0) o.bits1 = 8; if (o.bits2 == 0) o.bits2 = 8; }
+    if (o.probe_split == 0) {
+        // enough tasks to fill 256 CUs even when nothing is partitioned, at most 32 Ki probe tuples each
+        const u64 np = nR > nS ? nR : nS;
+        u64 ps = (np + 1023) / 1024;
+        ps = (ps + JOIN_TILE - 1) / JOIN_TILE * JOIN_TILE;
+        if (ps < (u64)JOIN_TILE) ps = JOIN_TILE;
+        if (ps > 32768) ps = 32768;
+        o.probe_split = (int32_t)ps;
+    }
+    *out = o;
+    return RHJ_OK;
+}
+
+PassGeom make_geom(u64 n, u32 nseg, int shift, int bits)
+{
+    PassGeom g;
+    g.n = n;
+    u64 L = (n + PART_TARGET_UNITS - 1) / PART_TARGET_UNITS;
+    L = (L + PART_TILE - 1) / PART_TILE * PART_TILE;
+    if (L < (u64)PART_TILE) L = PART_TILE;
+    g.L = L;
+    g.nseg = nseg;
+    g.max_units = (u32)(n / L) + nseg;
+    g.shift = shift;
+    g.bits = bits;
+    return g;
+}
+
+// One partition pass over all segments: histogram -> scan -> scatter.
+int run_pass(rhj_ctx *ctx, const void *d_in, void *d_out, u64 n, const u64 *d_seg_start, u32 nseg, int shift,
+             int bits, u64 *d_part_start)
+{
+    const PassGeom g = make_geom(n, nseg, shift, bits);
+    const size_t nbins = (size_t)1 << bits;
+    RHJCHK(ensure(ctx, ctx->unit_start, ((size_t)nseg + 1) * 4));
+    RHJCHK(ensure(ctx, ctx->unit_hist, (size_t)g.max_units * nbins * 4));
+    RHJCHK(ensure(ctx, ctx->unit_base, (size_t)g.max_units * nbins * 8));
+    u32 *unit_start = (u32 *)ctx->unit_start.p;
+    {
+        Span s(ctx, RHJ_K_AUX);
+        launch_make_units(ctx->stream, d_seg_start, nseg, g.L, unit_start);
+    }
+    {
+        Span s(ctx, RHJ_K_HIST);
+        launch_hist_units(ctx->stream, d_in, g, d_seg_start, unit_start, (u32 *)ctx->unit_hist.p);
+    }
+    {
+        Span s(ctx, RHJ_K_SCAN);
+        launch_scan_units(ctx->stream, g, d_seg_start, unit_start, (const u32 *)ctx->unit_hist.p,
+                          (u64 *)ctx->unit_base.p, d_part_start);
+    }
+    {
+        Span s(ctx, RHJ_K_SCATTER);
+        launch_scatter_units(ctx->stream, d_in, d_out, g, d_seg_start, unit_start, (const u64 *)ctx->unit_base.p);
+    }
+    return check_launch(ctx, "partition pass");
+}
+
+// Partition one relation with `passes` passes into d_out; boundaries into d_ps[2^(b1+b2) + 1].
+int partition_relation(rhj_ctx *ctx, const void *d_in, u64 n, int passes, int b1, int b2, void *d_out, u64 *d_ps)
+{
+    RHJCHK(ensure(ctx, ctx->seg0, 64));
+    u64 *seg0 = (u64 *)ctx->seg0.p;
+    {
+        Span s(ctx, RHJ_K_AUX);
+        // seg0 = {0, n}; the u32 pair behind it is scratch
+        launch_init_single_segment(ctx->stream, n, PART_TILE, seg0, (u32 *)(seg0 + 4));
+    }
+    if (passes == 1) return run_pass(ctx, d_in, d_out, n, seg0, 1, 0, b1, d_ps);
+    RHJCHK(ensure(ctx, ctx->part_tmp, (size_t)(n ? n : 1) * 16));
+    RHJCHK(ensure(ctx, ctx->ps_1, (((size_t)1 << b1) + 1) * 8));
+    RHJCHK(run_pass(ctx, d_in, ctx->part_tmp.p, n, seg0, 1, 0, b1, (u64 *)ctx->ps_1.p));
+    return run_pass(ctx, ctx->part_tmp.p, d_out, n, (const u64 *)ctx->ps_1.p, 1u << b1, b1, b2, d_ps);
+}
+
+// Partition phase of a join: leaves ctx->cur_* describing partitioned R and S.
+int partition_phase(rhj_ctx *ctx, const void *d_R, u64 nR, const void *d_S, u64 nS, const rhj_opts &plan)
+{
+    ctx->cur_nR = nR;
+    ctx->cur_nS = nS;
+    ctx->cur_probe_split = (u32)plan.probe_split;
+    ctx->last.passes = plan.passes;
+    ctx->last.bits1 = plan.bits1;
+    ctx->last.bits2 = plan.bits2;
+    if (plan.passes == 0) {
+        RHJCHK(ensure(ctx, ctx->ps_R, 64));
+        RHJCHK(ensure(ctx, ctx->ps_S, 64));
+        {
+            Span s(ctx, RHJ_K_AUX);
+            launch_init_single_segment(ctx->stream, nR, PART_TILE, (u64 *)ctx->ps_R.p, (u32 *)((u64 *)ctx->ps_R.p + 4));
+            launch_init_single_segment(ctx->stream, nS, PART_TILE, (u64 *)ctx->ps_S.p, (u32 *)((u64 *)ctx->ps_S.p + 4));
+        }
+        ctx->cur_R = d_R;
+        ctx->cur_S = d_S;
+        ctx->cur_nparts = 1;
+        ctx->cur_radix_bits = 0;
+    } else {
+        const int tb = plan.bits1 + (plan.passes == 2 ? plan.bits2 : 0);
+        const size_t np = (size_t)1 << tb;
+        RHJCHK(ensure(ctx, ctx->ps_R, (np + 1) * 8));
+        RHJCHK(ensure(ctx, ctx->ps_S, (np + 1) * 8));
+        RHJCHK(ensure(ctx, ctx->part_R, (size_t)(nR ? nR : 1) * 16));
+        RHJCHK(ensure(ctx, ctx->part_S, (size_t)(nS ? nS : 1) * 16));
+        RHJCHK(partition_relation(ctx, d_R, nR, plan.passes, plan.bits1, plan.bits2, ctx->part_R.p, (u64 *)ctx->ps_R.p));
+        RHJCHK(partition_relation(ctx, d_S, nS, plan.passes, plan.bits1, plan.bits2, ctx->part_S.p, (u64 *)ctx->ps_S.p));
+        ctx->cur_R = ctx->part_R.p;
+        ctx->cur_S = ctx->part_S.p;
+        ctx->cur_nparts = np;
+        ctx->cur_radix_bits = tb;
+    }
+    ctx->cur_psR = (const u64 *)ctx->ps_R.p;
+    ctx->cur_psS = (const u64 *)ctx->ps_S.p;
+    return check_launch(ctx, "partition phase");
+}
+
+// Join phase on explicit partitioned inputs.  Synchronises to read the exact result count.
+int join_phase_on(rhj_ctx *ctx, const void *d_Rp, const u64 *d_psR, u64 nR, const void *d_Sp, const u64 *d_psS,
+                  u64 nS, u64 nparts, int radix_bits, u32 probe_split, void *d_out, u64 cap, u64 *out_count)
+{
+    if (probe_split == 0) probe_split = 32768;
+    const u64 max_tasks64 = nparts + (nR + nS) / probe_split + 1;
+    if (max_tasks64 > 0x7fffffffull) return fail(ctx, RHJ_E_INVALID, "too many join tasks");
+    const u32 max_tasks = (u32)max_tasks64;
+    RHJCHK(ensure(ctx, ctx->tasks, (size_t)max_tasks * sizeof(JoinTask)));
+    RHJCHK(ensure(ctx, ctx->counters, 64));
+    u64 *d_count = (u64 *)ctx->counters.p;
+    u32 *d_ntasks = (u32 *)(d_count + 1);
+    {
+        Span s(ctx, RHJ_K_AUX);
+        HIPCHK(ctx, hipMemsetAsync(ctx->counters.p, 0, 64, ctx->stream));
+    }
+    {
+        Span s(ctx, RHJ_K_TASKS);
+        launch_make_tasks(ctx->stream, d_psR, d_psS, nparts, probe_split, (JoinTask *)ctx->tasks.p, d_ntasks, max_tasks);
+    }
+    {
+        Span s(ctx, RHJ_K_JOIN);
+        launch_join(ctx->stream, d_Rp, d_psR, d_Sp, d_psS, (const JoinTask *)ctx->tasks.p, d_ntasks, max_tasks,
+                    radix_bits, d_out, d_out ? cap : 0, d_count);
+    }
+    RHJCHK(check_launch(ctx, "join phase"));
+    u64 host[2] = {0, 0};
+    HIPCHK(ctx, hipMemcpyAsync(host, ctx->counters.p, 16, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    *out_count = host[0];
+    ctx->last.ntasks = (u32)(host[1] & 0xffffffffu);
+    return RHJ_OK;
+}
+
+int join_phase(rhj_ctx *ctx, void *d_out, u64 cap, u64 *out_count)
+{
+    return join_phase_on(ctx, ctx->cur_R, ctx->cur_psR, ctx->cur_nR, ctx->cur_S, ctx->cur_psS, ctx->cur_nS,
+                         ctx->cur_nparts, ctx->cur_radix_bits, ctx->cur_probe_split, d_out, cap, out_count);
+}
+
+}  // namespace
+
+// =================================================================================================
+// C-ABI
+// =================================================================================================
+extern "C" {
+
+int rhj_abi_version(void) { return RHJ_ABI_VERSION; }
+
+int rhj_device_count(void)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) { (void)hipGetLastError(); return 0; }
+    return n;
+}
+
+void rhj_default_opts(rhj_opts *o)
+{
+    if (!o) return;
+    o->passes = -1;
+    o->bits1 = 0;
+    o->bits2 = 0;
+    o->probe_split = 0;
+}
+
+int rhj_plan(uint64_t nR, uint64_t nS, const rhj_opts *in, rhj_opts *resolved)
+{
+    if (!resolved) return RHJ_E_INVALID;
+    return resolve_plan(nR, nS, in, resolved);
+}
+
+const char *rhj_last_error(const rhj_ctx *ctx) { return ctx ? ctx->err.c_str() : g_last_error.c_str(); }
+
+int rhj_init(int device, rhj_ctx **out_ctx)
+{
+    if (!out_ctx) return fail(nullptr, RHJ_E_INVALID, "out_ctx is null");
+    *out_ctx = nullptr;
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n <= 0) {
+        (void)hipGetLastError();
+        return fail(nullptr, RHJ_E_NODEVICE, "no HIP device available");
+    }
+    if (device < 0 || device >= n) return fail(nullptr, RHJ_E_INVALID, "device index out of range");
+    rhj_ctx *ctx = new rhj_ctx();
+    ctx->device = device;
+    if (hipSetDevice(device) != hipSuccess || hipStreamCreateWithFlags(&ctx->own_stream, hipStreamNonBlocking) != hipSuccess) {
+        (void)hipGetLastError();
+        delete ctx;
+        return fail(nullptr, RHJ_E_HIP, "cannot create a stream on the device");
+    }
+    ctx->stream = ctx->own_stream;
+    *out_ctx = ctx;
+    return RHJ_OK;
+}
+
+int rhj_release_workspace(rhj_ctx *ctx)
+{
+    RHJCHK(use_device(ctx));
+    (void)hipStreamSynchronize(ctx->stream);
+    DevBuf *all[] = {&ctx->in_R, &ctx->in_S, &ctx->part_R, &ctx->part_S, &ctx->part_tmp, &ctx->ps_R, &ctx->ps_S,
+                     &ctx->ps_1, &ctx->seg0, &ctx->unit_start, &ctx->unit_hist, &ctx->unit_base, &ctx->tasks,
+                     &ctx->counters, &ctx->out_pairs, &ctx->hist_tmp};
+    for (DevBuf *b : all) release(*b);
+    return RHJ_OK;
+}
+
+void rhj_destroy(rhj_ctx *ctx)
+{
+    if (!ctx) return;
+    (void)hipSetDevice(ctx->device);
+    (void)rhj_release_workspace(ctx);
+    for (hipEvent_t ev : ctx->prof.pool) (void)hipEventDestroy(ev);
+    if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
+    delete ctx;
+}
+
+int rhj_set_stream(rhj_ctx *ctx, void *hip_stream)
+{
+    RHJCHK(use_device(ctx));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    ctx->stream = hip_stream ? (hipStream_t)hip_stream : ctx->own_stream;
+    return RHJ_OK;
+}
+
+int rhj_set_profiling(rhj_ctx *ctx, int enabled)
+{
+    if (!ctx) return RHJ_E_INVALID;
+    ctx->prof.on = enabled != 0;
+    prof_reset(ctx);
+    return RHJ_OK;
+}
+
+int rhj_get_timings(rhj_ctx *ctx, rhj_timings *out)
+{
+    if (!ctx || !out) return RHJ_E_INVALID;
+    RHJCHK(use_device(ctx));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    rhj_timings t = ctx->last;
+    for (int k = 0; k < RHJ_K_COUNT; k++) { t.ms[k] = 0; t.launches[k] = 0; }
+    Prof &p = ctx->prof;
+    for (size_t i = 0; i < p.used; i++) {
+        float ms = 0;
+        if (hipEventElapsedTime(&ms, p.pool[2 * i], p.pool[2 * i + 1]) != hipSuccess) { (void)hipGetLastError(); continue; }
+        t.ms[p.kinds[i]] += ms;
+        t.launches[p.kinds[i]]++;
+    }
+    if (p.used) {
+        float ms = 0;
+        if (hipEventElapsedTime(&ms, p.pool[0], p.pool[2 * (p.used - 1) + 1]) == hipSuccess) t.total_ms = ms;
+    }
+    *out = t;
+    return RHJ_OK;
+}
+
+int rhj_sync(rhj_ctx *ctx)
+{
+    RHJCHK(use_device(ctx));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    return RHJ_OK;
+}
+
+int rhj_reserve(rhj_ctx *ctx, uint64_t nR, uint64_t nS, const rhj_opts *opts)
+{
+    RHJCHK(use_device(ctx));
+    rhj_opts plan;
+    if (resolve_plan(nR, nS, opts, &plan) != RHJ_OK) return fail(ctx, RHJ_E_INVALID, "bad rhj_opts");
+    if (plan.passes >= 1) {
+        RHJCHK(ensure(ctx, ctx->part_R, (size_t)(nR ? nR : 1) * 16));
+        RHJCHK(ensure(ctx, ctx->part_S, (size_t)(nS ? nS : 1) * 16));
+    }
+    if (plan.passes == 2) RHJCHK(ensure(ctx, ctx->part_tmp, (size_t)((nR > nS ? nR : nS) + 1) * 16));
+    return RHJ_OK;
+}
+
+int rhj_join_dev(rhj_ctx *ctx, const rhj_tuple *d_R, uint64_t nR, const rhj_tuple *d_S, uint64_t nS,
+                 const rhj_opts *opts, rhj_pair *d_out, uint64_t out_capacity, uint64_t *out_count)
+{
+    RHJCHK(use_device(ctx));
+    if (!out_count) return fail(ctx, RHJ_E_INVALID, "out_count is null");
+    *out_count = 0;
+    prof_reset(ctx);
+    if (nR == 0 || nS == 0) return RHJ_OK;            // nothing to schedule (Result.cpp:101 never fires)
+    if (!d_R || !d_S) return fail(ctx, RHJ_E_INVALID, "null input relation");
+    rhj_opts plan;
+    if (resolve_plan(nR, nS, opts, &plan) != RHJ_OK) return fail(ctx, RHJ_E_INVALID, "bad rhj_opts");
+    RHJCHK(partition_phase(ctx, d_R, nR, d_S, nS, plan));
+    RHJCHK(join_phase(ctx, d_out, d_out ? out_capacity : 0, (u64 *)out_count));
+    if (d_out && *out_count > out_capacity) return fail(ctx, RHJ_E_OVERFLOW, "result buffer too small");
+    return RHJ_OK;
+}
+
+int rhj_join(rhj_ctx *ctx, const rhj_tuple *R, uint64_t nR, const rhj_tuple *S, uint64_t nS,
+             const rhj_opts *opts, void **out_page, uint64_t *out_count)
+{
+    RHJCHK(use_device(ctx));
+    if (!out_page || !out_count) return fail(ctx, RHJ_E_INVALID, "null output argument");
+    *out_page = nullptr;
+    *out_count = 0;
+    prof_reset(ctx);
+    if (nR == 0 || nS == 0) return RHJ_OK;
+    if (!R || !S) return fail(ctx, RHJ_E_INVALID, "null input relation");
+    rhj_opts plan;
+    if (resolve_plan(nR, nS, opts, &plan) != RHJ_OK) return fail(ctx, RHJ_E_INVALID, "bad rhj_opts");
+    RHJCHK(ensure(ctx, ctx->in_R, (size_t)nR * 16));
+    RHJCHK(ensure(ctx, ctx->in_S, (size_t)nS * 16));
+    HIPCHK(ctx, hipMemcpyAsync(ctx->in_R.p, R, (size_t)nR * 16, hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(ctx, hipMemcpyAsync(ctx->in_S.p, S, (size_t)nS * 16, hipMemcpyHostToDevice, ctx->stream));
+    RHJCHK(partition_phase(ctx, ctx->in_R.p, nR, ctx->in_S.p, nS, plan));
+    // optimistic capacity: a foreign-key join yields about max(|R|,|S|) pairs; the count is exact
+    // either way, and an overflow only repeats the join phase (partitions stay in the workspace)
+    u64 cap = (nR > nS ? nR : nS) + 1024;
+    RHJCHK(ensure(ctx, ctx->out_pairs, (size_t)cap * 16));
+    cap = ctx->out_pairs.cap / 16;
+    u64 count = 0;
+    RHJCHK(join_phase(ctx, ctx->out_pairs.p, cap, &count));
+    if (count > cap) {
+        RHJCHK(ensure(ctx, ctx->out_pairs, (size_t)count * 16));
+        cap = ctx->out_pairs.cap / 16;
+        u64 again = 0;
+        RHJCHK(join_phase(ctx, ctx->out_pairs.p, cap, &again));
+        if (again != count) return fail(ctx, RHJ_E_HIP, "result count changed between join phases");
+    }
+    if (count == 0) return RHJ_OK;                    // head stays nullptr (Result::isEmpty)
+    unsigned char *page = (unsigned char *)malloc(8 + (size_t)count * 16);
+    if (!page) return fail(ctx, RHJ_E_NOMEM, "malloc of the result page failed");
+    memset(page, 0, 8);                               // bucket_info::next = nullptr (Result.h:14-17)
+    HIPCHK(ctx, hipMemcpyAsync(page + 8, ctx->out_pairs.p, (size_t)count * 16, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    *out_page = page;
+    *out_count = count;
+    return RHJ_OK;
+}
+
+// ---- stage entry points ---------------------------------------------------------------------------
+int rhj_partition(rhj_ctx *ctx, const rhj_tuple *d_in, uint64_t n, int bits1, int bits2, rhj_tuple *d_out,
+                  uint64_t *d_part_start)
+{
+    RHJCHK(use_device(ctx));
+    if (bits1 < 1 || bits1 > PART_MAX_BITS || bits2 < 0 || bits2 > PART_MAX_BITS || !d_out || !d_part_start || (n && !d_in))
+        return fail(ctx, RHJ_E_INVALID, "bad rhj_partition argument");
+    prof_reset(ctx);
+    return partition_relation(ctx, d_in, n, bits2 ? 2 : 1, bits1, bits2, d_out, (u64 *)d_part_start);
+}
+
+int rhj_histogram(rhj_ctx *ctx, const rhj_tuple *d_rel, uint64_t n, int shift, int bits, uint64_t *d_hist)
+{
+    RHJCHK(use_device(ctx));
+    if (bits < 1 || bits > PART_MAX_BITS || shift < 0 || shift + bits > 64 || !d_hist || (n && !d_rel))
+        return fail(ctx, RHJ_E_INVALID, "bad rhj_histogram argument");
+    prof_reset(ctx);
+    const size_t nbins = (size_t)1 << bits;
+    RHJCHK(ensure(ctx, ctx->seg0, 64));
+    RHJCHK(ensure(ctx, ctx->hist_tmp, (nbins + 1) * 8));
+    u64 *seg0 = (u64 *)ctx->seg0.p;
+    const PassGeom g = make_geom(n, 1, shift, bits);
+    RHJCHK(ensure(ctx, ctx->unit_start, 8));
+    RHJCHK(ensure(ctx, ctx->unit_hist, (size_t)g.max_units * nbins * 4));
+    RHJCHK(ensure(ctx, ctx->unit_base, (size_t)g.max_units * nbins * 8));
+    {
+        Span s(ctx, RHJ_K_AUX);
+        launch_init_single_segment(ctx->stream, n, g.L, seg0, (u32 *)ctx->unit_start.p);
+    }
+    {
+        Span s(ctx, RHJ_K_HIST);
+        launch_hist_units(ctx->stream, d_rel, g, seg0, (const u32 *)ctx->unit_start.p, (u32 *)ctx->unit_hist.p);
+    }
+    {
+        Span s(ctx, RHJ_K_SCAN);
+        launch_scan_units(ctx->stream, g, seg0, (const u32 *)ctx->unit_start.p, (const u32 *)ctx->unit_hist.p,
+                          (u64 *)ctx->unit_base.p, (u64 *)ctx->hist_tmp.p);
+        launch_diff_hist(ctx->stream, (const u64 *)ctx->hist_tmp.p, nbins, (u64 *)d_hist);
+    }
+    return check_launch(ctx, "rhj_histogram");
+}
+
+int rhj_prefix(rhj_ctx *ctx, const uint64_t *d_hist, uint64_t nbins, uint64_t *d_start)
+{
+    RHJCHK(use_device(ctx));
+    if (!d_hist || !d_start || nbins == 0) return fail(ctx, RHJ_E_INVALID, "bad rhj_prefix argument");
+    prof_reset(ctx);
+    {
+        Span s(ctx, RHJ_K_SCAN);
+        launch_prefix(ctx->stream, (const u64 *)d_hist, nbins, (u64 *)d_start);
+    }
+    return check_launch(ctx, "rhj_prefix");
+}
+
+int rhj_bucket_join(rhj_ctx *ctx, const rhj_tuple *d_Rp, const uint64_t *d_startR, const rhj_tuple *d_Sp,
+                    const uint64_t *d_startS, uint64_t nparts, int radix_bits, int probe_split, rhj_pair *d_out,
+                    uint64_t out_capacity, uint64_t *out_count)
+{
+    RHJCHK(use_device(ctx));
+    if (!d_startR || !d_startS || !out_count || nparts == 0 || radix_bits < 0 || radix_bits > 40 || probe_split < 0)
+        return fail(ctx, RHJ_E_INVALID, "bad rhj_bucket_join argument");
+    prof_reset(ctx);
+    // sizes are the last boundary of each side
+    u64 ends[2] = {0, 0};
+    HIPCHK(ctx, hipMemcpyAsync(&ends[0], d_startR + nparts, 8, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipMemcpyAsync(&ends[1], d_startS + nparts, 8, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    *out_count = 0;
+    if (ends[0] == 0 || ends[1] == 0) return RHJ_OK;
+    RHJCHK(join_phase_on(ctx, d_Rp, (const u64 *)d_startR, ends[0], d_Sp, (const u64 *)d_startS, ends[1], nparts,
+                         radix_bits, (u32)probe_split, d_out, out_capacity, (u64 *)out_count));
+    if (d_out && *out_count > out_capacity) return fail(ctx, RHJ_E_OVERFLOW, "result buffer too small");
+    return RHJ_OK;
+}
+
+// ---- utilities --------------------------------------------------------------------------------------
+static int reduce_to_host(rhj_ctx *ctx, uint64_t *host_out, void (*launch)(hipStream_t, const void *, u64, u64 *),
+                          const void *d_in, u64 n)
+{
+    RHJCHK(ensure(ctx, ctx->counters, 64));
+    u64 *d_sum = (u64 *)ctx->counters.p + 4;
+    HIPCHK(ctx, hipMemsetAsync(d_sum, 0, 8, ctx->stream));
+    if (n) {
+        Span s(ctx, RHJ_K_AUX);
+        launch(ctx->stream, d_in, n, d_sum);
+    }
+    RHJCHK(check_launch(ctx, "reduction"));
+    HIPCHK(ctx, hipMemcpyAsync(host_out, d_sum, 8, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    return RHJ_OK;
+}
+
+int rhj_pairs_checksum_dev(rhj_ctx *ctx, const rhj_pair *d_pairs, uint64_t n, uint64_t *checksum)
+{
+    RHJCHK(use_device(ctx));
+    if (!checksum || (n && !d_pairs)) return fail(ctx, RHJ_E_INVALID, "bad rhj_pairs_checksum_dev argument");
+    return reduce_to_host(ctx, checksum, launch_checksum, d_pairs, n);
+}
+
+int rhj_expected_pkfk_dev(rhj_ctx *ctx, const rhj_tuple *d_S, uint64_t n, uint64_t *count, uint64_t *checksum)
+{
+    RHJCHK(use_device(ctx));
+    if (!checksum || !count || (n && !d_S)) return fail(ctx, RHJ_E_INVALID, "bad rhj_expected_pkfk_dev argument");
+    *count = n;
+    return reduce_to_host(ctx, checksum, launch_expected_pkfk, d_S, n);
+}
+
+int rhj_generate_dev(rhj_ctx *ctx, int kind, rhj_tuple *d_out, uint64_t n, uint64_t row0, uint64_t D, uint64_t seed,
+                     int theta_milli)
+{
+    RHJCHK(use_device(ctx));
+    if (kind < 0 || kind > 4 || (n && !d_out) || (kind != 4 && D == 0) || (kind == 2 && theta_milli == 1000))
+        return fail(ctx, RHJ_E_INVALID, "bad rhj_generate_dev argument");
+    if (n) {
+        Span s(ctx, RHJ_K_AUX);
+        launch_generate(ctx->stream, kind, d_out, n, row0, D, seed, theta_milli / 1000.0);
+    }
+    return check_launch(ctx, "rhj_generate_dev");
+}
+
+int rhj_dev_alloc(rhj_ctx *ctx, uint64_t bytes, void **d_ptr)
+{
+    RHJCHK(use_device(ctx));
+    if (!d_ptr) return fail(ctx, RHJ_E_INVALID, "d_ptr is null");
+    *d_ptr = nullptr;
+    hipError_t e = hipMalloc(d_ptr, bytes ? bytes : 16);
+    if (e != hipSuccess) {
+        (void)hipGetLastError();
+        *d_ptr = nullptr;
+        return fail(ctx, RHJ_E_NOMEM, std::string("hipMalloc: ") + hipGetErrorString(e));
+    }
+    return RHJ_OK;
+}
+
+int rhj_dev_free(rhj_ctx *ctx, void *d_ptr)
+{
+    RHJCHK(use_device(ctx));
+    if (d_ptr) HIPCHK(ctx, hipFree(d_ptr));
+    return RHJ_OK;
+}
+
+int rhj_copy_h2d(rhj_ctx *ctx, void *d_dst, const void *src, uint64_t bytes)
+{
+    RHJCHK(use_device(ctx));
+    if (bytes) {
+        HIPCHK(ctx, hipMemcpyAsync(d_dst, src, bytes, hipMemcpyHostToDevice, ctx->stream));
+        HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    }
+    return RHJ_OK;
+}
+
+int rhj_copy_d2h(rhj_ctx *ctx, void *dst, const void *d_src, uint64_t bytes)
+{
+    RHJCHK(use_device(ctx));
+    if (bytes) {
+        HIPCHK(ctx, hipMemcpyAsync(dst, d_src, bytes, hipMemcpyDeviceToHost, ctx->stream));
+        HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    }
+    return RHJ_OK;
+}
+
+int rhj_dev_mem_info(rhj_ctx *ctx, uint64_t *free_bytes, uint64_t *total_bytes)
+{
+    RHJCHK(use_device(ctx));
+    size_t f = 0, t = 0;
+    HIPCHK(ctx, hipMemGetInfo(&f, &t));
+    if (free_bytes) *free_bytes = f;
+    if (total_bytes) *total_bytes = t;
+    return RHJ_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,63 @@
+// rhj_internal.h -- shared between rhj_kernels.hip (device code + launchers) and rhj_api.hip (C-ABI).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+typedef unsigned long long u64;
+typedef unsigned int u32;
+
+// ---- partition pass geometry ------------------------------------------------------------------
+// A pass partitions every SEGMENT of the input (pass 1: the whole relation; pass 2: each pass-1
+// bucket) by `bits` radix bits.  A segment is cut into UNITS of at most L tuples; one workgroup
+// owns one unit in the histogram kernel and again in the scatter kernel (the reference's row
+// ranges, structs.cpp:146-161, with ranges = units instead of 8 threads).
+constexpr int PART_THREADS = 512;                 // 8 wavefronts
+constexpr int PART_TPT = 8;                       // tuples per thread per tile
+constexpr int PART_TILE = PART_THREADS * PART_TPT;  // 4096 tuples = 64 KiB LDS staging
+constexpr int PART_MAX_BITS = 10;                 // k_scan_units: nbins <= 1024 threads
+constexpr u32 PART_TARGET_UNITS = 2048;           // ~8 units per CU
+
+// ---- bucket join geometry -----------------------------------------------------------------------
+constexpr int JOIN_THREADS = 1024;                // 16 wavefronts, one workgroup per CU
+constexpr int JOIN_CHUNK = 6144;                  // build tuples per LDS hash table (96 KiB keys+rowids)
+constexpr int JOIN_HEADS = 8192;                  // chain heads (32 KiB)
+constexpr int JOIN_EPT = 4;                       // probe tuples per thread per tile
+constexpr int JOIN_TILE = JOIN_THREADS * JOIN_EPT;
+constexpr int JOIN_FILL_NUM = 3, JOIN_FILL_DEN = 4;  // plan: average build partition <= 3/4 chunk
+
+struct JoinTask {           // one workgroup's work: probe range [pbeg, pbeg+plen) of partition `part`
+    u64 pbeg;
+    u32 plen;
+    u32 part;
+};
+
+struct PassGeom {
+    u64 n;          // tuples in the relation
+    u64 L;          // max tuples per unit
+    u32 nseg;       // segments in this pass
+    u32 max_units;  // grid size upper bound: floor(n / L) + nseg
+    int shift;      // digit = (payload >> shift) & (nbins-1)
+    int bits;
+};
+
+// launchers (all asynchronous on `st`)
+void launch_init_single_segment(hipStream_t st, u64 n, u64 L, u64 *d_seg_start, u32 *d_unit_start);
+void launch_make_units(hipStream_t st, const u64 *d_seg_start, u32 nseg, u64 L, u32 *d_unit_start);
+void launch_hist_units(hipStream_t st, const void *d_in, const PassGeom &g, const u64 *d_seg_start,
+                       const u32 *d_unit_start, u32 *d_unit_hist);
+void launch_scan_units(hipStream_t st, const PassGeom &g, const u64 *d_seg_start, const u32 *d_unit_start,
+                       const u32 *d_unit_hist, u64 *d_unit_base, u64 *d_part_start);
+void launch_scatter_units(hipStream_t st, const void *d_in, void *d_out, const PassGeom &g,
+                          const u64 *d_seg_start, const u32 *d_unit_start, const u64 *d_unit_base);
+void launch_diff_hist(hipStream_t st, const u64 *d_start, u64 nbins, u64 *d_hist);
+void launch_prefix(hipStream_t st, const u64 *d_hist, u64 nbins, u64 *d_start);
+void launch_make_tasks(hipStream_t st, const u64 *d_startR, const u64 *d_startS, u64 nparts, u32 probe_split,
+                       JoinTask *d_tasks, u32 *d_ntasks, u32 max_tasks);
+void launch_join(hipStream_t st, const void *d_R, const u64 *d_startR, const void *d_S, const u64 *d_startS,
+                 const JoinTask *d_tasks, const u32 *d_ntasks, u32 grid, int radix_bits,
+                 void *d_out, u64 out_capacity, u64 *d_out_count);
+void launch_checksum(hipStream_t st, const void *d_pairs, u64 n, u64 *d_sum);
+void launch_generate(hipStream_t st, int kind, void *d_out, u64 n, u64 row0, u64 D, u64 seed, double theta);
+void launch_expected_pkfk(hipStream_t st, const void *d_S, u64 n, u64 *d_sum);
+size_t join_lds_bytes();
+size_t part_lds_bytes(int bits);

@@ -1,0 +1,673 @@
+// rhj_kernels.hip -- hand-written gfx950 (CDNA4, wave64) kernels of the radix hash join.
+//
+// Kernel                 replaces (reference file:line)                          bound
+// k_hist_units           HistogramJob::run            JobScheduler.cpp:149-155     HBM read  (16 B/tuple)
+// k_scan_units           hist reduce + range prefix   structs.cpp:168-173,
+//                                                     JobScheduler.cpp:163-169     latency (KBs)
+// k_scatter_units        PartitionJob scatter + the   JobScheduler.cpp:170-174,
+//                        serial merge-gather          structs.cpp:183-194          HBM read+write (32 B/tuple)
+// k_make_tasks           JoinJob scheduling loop      Result.cpp:98-107            latency
+// k_join                 JoinJob::run, join_buckets,  JobScheduler.cpp:186-192,
+//                        add_result / addAll          Result.cpp:43-76, 21-35      HBM read+write (16 B/tuple + 16 B/pair)
+//
+// No MFMA anywhere: the path is 64-bit integer hashing and data movement, bounded by HBM.
+#include "rhj_internal.h"
+
+namespace {
+
+struct __align__(16) Tup { u64 key; u64 payload; };   // reference structs.h:33-36
+struct __align__(16) Pair { u64 r; u64 s; };          // reference Result.h:9-12
+
+__device__ __forceinline__ u64 mix64(u64 z)
+{
+    z += 0x9E3779B97F4A7C15ULL;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ULL;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBULL;
+    return z ^ (z >> 31);
+}
+
+__device__ __forceinline__ u64 unmix64(u64 x)      // inverse of mix64
+{
+    x ^= (x >> 31) ^ (x >> 62);
+    x *= 0x319642B2D24D8EC3ULL;
+    x ^= (x >> 27) ^ (x >> 54);
+    x *= 0x96DE1B173F119089ULL;
+    x ^= (x >> 30) ^ (x >> 60);
+    return x - 0x9E3779B97F4A7C15ULL;
+}
+
+// inclusive scan over the 64 lanes of a wavefront
+__device__ __forceinline__ u32 wave_incl_scan(u32 v, int lane)
+{
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        u32 t = __shfl_up(v, off, 64);
+        if (lane >= off) v += t;
+    }
+    return v;
+}
+
+// Workgroup exclusive scan. wsum: LDS scratch of THREADS/64 words. Ends with a barrier, so wsum
+// may be reused immediately by the caller.
+template <int THREADS>
+__device__ __forceinline__ u32 block_excl_scan(u32 v, u32 *wsum, u32 &total)
+{
+    constexpr int NW = THREADS / 64;
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const u32 inc = wave_incl_scan(v, lane);
+    if (lane == 63) wsum[w] = inc;
+    __syncthreads();
+    u32 base = 0, tot = 0;
+#pragma unroll
+    for (int i = 0; i < NW; i++) {
+        const u32 s = wsum[i];
+        if (i < w) base += s;
+        tot += s;
+    }
+    __syncthreads();
+    total = tot;
+    return base + inc - v;
+}
+
+// unit u -> segment s with unit_start[s] <= u < unit_start[s+1]  (unit_start has nseg+1 entries)
+__device__ __forceinline__ u32 find_segment(const u32 *__restrict__ unit_start, u32 nseg, u32 u)
+{
+    u32 lo = 0, hi = nseg;     // invariant: unit_start[lo] <= u < unit_start[hi]
+    while (hi - lo > 1) {
+        const u32 mid = (lo + hi) >> 1;
+        if (unit_start[mid] <= u) lo = mid; else hi = mid;
+    }
+    return lo;
+}
+
+// ------------------------------------------------------------------------------------------------
+// unit tables
+// ------------------------------------------------------------------------------------------------
+__global__ void k_init_single_segment(u64 n, u64 L, u64 *seg_start, u32 *unit_start)
+{
+    if (threadIdx.x == 0) {
+        seg_start[0] = 0; seg_start[1] = n;
+        unit_start[0] = 0; unit_start[1] = (u32)((n + L - 1) / L);
+    }
+}
+
+// unit_start[s] = sum_{s'<s} ceil(size(s') / L), one workgroup, nseg arbitrary
+__global__ void __launch_bounds__(1024) k_make_units(const u64 *__restrict__ seg_start, u32 nseg, u64 L,
+                                                     u32 *__restrict__ unit_start)
+{
+    __shared__ u32 wsum[16];
+    __shared__ u32 carry;
+    if (threadIdx.x == 0) carry = 0;
+    __syncthreads();
+    for (u32 base = 0; base < nseg; base += 1024) {
+        const u32 s = base + threadIdx.x;
+        u32 v = 0;
+        if (s < nseg) v = (u32)((seg_start[s + 1] - seg_start[s] + L - 1) / L);
+        u32 tot;
+        const u32 ex = block_excl_scan<1024>(v, wsum, tot);
+        const u32 c = carry;
+        if (s < nseg) unit_start[s] = c + ex;
+        __syncthreads();
+        if (threadIdx.x == 0) carry = c + tot;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) unit_start[nseg] = carry;
+}
+
+// ------------------------------------------------------------------------------------------------
+// K1: radix histogram per unit.  HistogramJob::run (JobScheduler.cpp:149-155): hist[payload & mask]++
+// over a row range.  16 B/lane coalesced loads (the rowID rides along in the same 128 B line),
+// LDS histogram per workgroup, one flush per unit.
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(PART_THREADS)
+k_hist_units(const Tup *__restrict__ in, const u64 *__restrict__ seg_start, const u32 *__restrict__ unit_start,
+             u32 nseg, u64 L, int shift, int bits, u32 *__restrict__ unit_hist)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    u32 *cnt = reinterpret_cast<u32 *>(smem);
+    const u32 nbins = 1u << bits, mask = nbins - 1;
+    const u32 u = blockIdx.x;
+    if (u >= unit_start[nseg]) return;
+    const u32 s = find_segment(unit_start, nseg, u);
+    const u64 beg = seg_start[s] + (u64)(u - unit_start[s]) * L;
+    const u64 send = seg_start[s + 1];
+    const u64 end = (beg + L < send) ? beg + L : send;
+
+    for (u32 b = threadIdx.x; b < nbins; b += PART_THREADS) cnt[b] = 0;
+    __syncthreads();
+
+    u64 i = beg + threadIdx.x;
+    // 4 independent 16 B loads in flight per lane
+    for (; i + 3ull * PART_THREADS < end; i += 4ull * PART_THREADS) {
+        const Tup t0 = in[i], t1 = in[i + PART_THREADS], t2 = in[i + 2 * PART_THREADS], t3 = in[i + 3 * PART_THREADS];
+        atomicAdd(&cnt[(u32)(t0.payload >> shift) & mask], 1u);
+        atomicAdd(&cnt[(u32)(t1.payload >> shift) & mask], 1u);
+        atomicAdd(&cnt[(u32)(t2.payload >> shift) & mask], 1u);
+        atomicAdd(&cnt[(u32)(t3.payload >> shift) & mask], 1u);
+    }
+    for (; i < end; i += PART_THREADS) atomicAdd(&cnt[(u32)(in[i].payload >> shift) & mask], 1u);
+    __syncthreads();
+    u32 *out = unit_hist + (u64)u * nbins;
+    for (u32 b = threadIdx.x; b < nbins; b += PART_THREADS) out[b] = cnt[b];
+}
+
+// ------------------------------------------------------------------------------------------------
+// K2: per segment, turn unit histograms into absolute write cursors.
+//   part_start[s*nbins + d] = seg_start[s] + sum_{d'<d} total(s,d')         (the global histogram's
+//       exclusive prefix, structs.cpp:168-173 + JobScheduler.cpp:163-169)
+//   unit_base[u*nbins + d]  = part_start[s*nbins+d] + sum_{u'<u in s} hist[u'][d]  (each range's own
+//       cursor: what PartitionJob's local prefix + the bucket-major/range-minor merge amount to)
+// One workgroup (1024 threads = G groups x nbins digits) per segment; nbins <= 1024.
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(1024)
+k_scan_units(const u64 *__restrict__ seg_start, const u32 *__restrict__ unit_start, u32 nseg, int bits,
+             const u32 *__restrict__ unit_hist, u64 *__restrict__ unit_base, u64 *__restrict__ part_start, u64 n_total)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    u32 *part = reinterpret_cast<u32 *>(smem);          // [G][nbins] partial sums
+    __shared__ u32 wsum[16];
+    const u32 nbins = 1u << bits;
+    const u32 G = 1024u / nbins;                        // >= 1
+    const u32 s = blockIdx.x;
+    const u32 d = threadIdx.x & (nbins - 1), g = threadIdx.x >> bits;
+    const u32 us = unit_start[s], ue = unit_start[s + 1];
+    const u32 nu = ue - us, per = (nu + G - 1) / G;
+    const u32 gb = us + ((g * per < nu) ? g * per : nu);
+    const u32 ge = us + (((g + 1) * per < nu) ? (g + 1) * per : nu);
+
+    u32 sum = 0;
+    for (u32 u = gb; u < ge; u++) sum += unit_hist[(u64)u * nbins + d];
+    part[g * nbins + d] = sum;
+    __syncthreads();
+    u32 tot_d = 0, before = 0;
+    for (u32 k = 0; k < G; k++) {
+        const u32 p = part[k * nbins + d];
+        tot_d += p;
+        if (k < g) before += p;
+    }
+    u32 dummy;
+    const u32 ex = block_excl_scan<1024>(g == 0 ? tot_d : 0u, wsum, dummy);
+    // threads of group 0 hold the digit-exclusive prefix; publish through LDS for the other groups
+    __syncthreads();
+    if (g == 0) part[d] = ex;       // part[0][*] no longer needed: every thread has read its column
+    __syncthreads();
+    const u64 pstart = seg_start[s] + part[d];
+    if (g == 0) {
+        part_start[(u64)s * nbins + d] = pstart;
+        if (s == nseg - 1 && d == nbins - 1) part_start[(u64)nseg * nbins] = n_total;
+    }
+    u64 run = pstart + before;
+    for (u32 u = gb; u < ge; u++) {
+        unit_base[(u64)u * nbins + d] = run;
+        run += unit_hist[(u64)u * nbins + d];
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// K3: scatter-partition one unit, tile by tile.  PartitionJob::run's scatter (JobScheduler.cpp:170-174)
+// fused with the serial merge-gather of structs.cpp:183-194: tuples go straight to their final
+// slot of R'.  Per 4096-tuple tile: coalesced 16 B loads -> LDS rank per digit -> tile re-ordered
+// by digit in LDS -> each digit's run written as consecutive 16 B stores (write combining:
+// average run = TILE/nbins tuples; consecutive tiles of a unit extend the same nbins streams, so
+// partial 128 B lines complete in the same XCD's L2).
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(PART_THREADS)
+k_scatter_units(const Tup *__restrict__ in, Tup *__restrict__ out, const u64 *__restrict__ seg_start,
+                const u32 *__restrict__ unit_start, u32 nseg, u64 L, int shift, int bits,
+                const u64 *__restrict__ unit_base)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const u32 nbins = 1u << bits, mask = nbins - 1;
+    Tup *tile = reinterpret_cast<Tup *>(smem);                               // PART_TILE * 16 B
+    u64 *gbase = reinterpret_cast<u64 *>(smem + (size_t)PART_TILE * 16);     // nbins * 8
+    u32 *cnt = reinterpret_cast<u32 *>(gbase + nbins);                       // nbins * 4
+    u32 *excl = cnt + nbins;                                                 // nbins * 4
+    u32 *wsum = excl + nbins;                                                // PART_THREADS/64 * 4
+
+    const u32 u = blockIdx.x;
+    if (u >= unit_start[nseg]) return;
+    const u32 s = find_segment(unit_start, nseg, u);
+    const u64 beg = seg_start[s] + (u64)(u - unit_start[s]) * L;
+    const u64 send = seg_start[s + 1];
+    const u64 end = (beg + L < send) ? beg + L : send;
+    const int tid = threadIdx.x;
+    // bins per thread for the in-LDS exclusive scan (consecutive bins)
+    const u32 bpt = (nbins + PART_THREADS - 1) / PART_THREADS;
+
+    for (u32 b = tid; b < nbins; b += PART_THREADS) { gbase[b] = unit_base[(u64)u * nbins + b]; cnt[b] = 0; }
+    __syncthreads();
+
+    for (u64 tb = beg; tb < end; tb += PART_TILE) {
+        const u32 ntile = (end - tb < (u64)PART_TILE) ? (u32)(end - tb) : (u32)PART_TILE;
+        Tup t[PART_TPT];
+        u32 rk[PART_TPT];
+#pragma unroll
+        for (int k = 0; k < PART_TPT; k++) {
+            const u32 i = k * PART_THREADS + tid;
+            if (i < ntile) t[k] = in[tb + i];
+        }
+#pragma unroll
+        for (int k = 0; k < PART_TPT; k++) {
+            const u32 i = k * PART_THREADS + tid;
+            if (i < ntile) rk[k] = atomicAdd(&cnt[(u32)(t[k].payload >> shift) & mask], 1u);
+        }
+        __syncthreads();
+        {   // exclusive scan of cnt -> excl
+            u32 loc = 0;
+            const u32 b0 = tid * bpt;
+            for (u32 j = 0; j < bpt; j++) if (b0 + j < nbins) loc += cnt[b0 + j];
+            u32 tot;
+            u32 ex = block_excl_scan<PART_THREADS>(loc, wsum, tot);
+            for (u32 j = 0; j < bpt; j++) if (b0 + j < nbins) { excl[b0 + j] = ex; ex += cnt[b0 + j]; }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < PART_TPT; k++) {
+            const u32 i = k * PART_THREADS + tid;
+            if (i < ntile) tile[excl[(u32)(t[k].payload >> shift) & mask] + rk[k]] = t[k];
+        }
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < PART_TPT; k++) {
+            const u32 i = k * PART_THREADS + tid;
+            if (i < ntile) {
+                const Tup v = tile[i];
+                const u32 dg = (u32)(v.payload >> shift) & mask;
+                out[gbase[dg] + (i - excl[dg])] = v;
+            }
+        }
+        __syncthreads();
+        for (u32 b = tid; b < nbins; b += PART_THREADS) { gbase[b] += cnt[b]; cnt[b] = 0; }
+        __syncthreads();
+    }
+}
+
+// d_hist[b] = d_start[b+1] - d_start[b]
+__global__ void k_diff_hist(const u64 *__restrict__ start, u64 nbins, u64 *__restrict__ hist)
+{
+    const u64 b = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (b < nbins) hist[b] = start[b + 1] - start[b];
+}
+
+// exclusive prefix of a uint64 histogram, one workgroup, any nbins (JobScheduler.cpp:163-169)
+__global__ void __launch_bounds__(1024) k_prefix(const u64 *__restrict__ hist, u64 nbins, u64 *__restrict__ start)
+{
+    __shared__ u64 wtot[16];
+    __shared__ u64 carry;
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    if (threadIdx.x == 0) carry = 0;
+    __syncthreads();
+    for (u64 base = 0; base < nbins; base += 1024) {
+        const u64 b = base + threadIdx.x;
+        const u64 v = (b < nbins) ? hist[b] : 0;
+        u64 inc = v;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const u64 t = __shfl_up(inc, off, 64);
+            if (lane >= off) inc += t;
+        }
+        if (lane == 63) wtot[w] = inc;
+        __syncthreads();
+        u64 pre = 0, tot = 0;
+        for (int i = 0; i < 16; i++) { const u64 x = wtot[i]; if (i < w) pre += x; tot += x; }
+        const u64 c = carry;
+        if (b < nbins) start[b] = c + pre + inc - v;
+        __syncthreads();
+        if (threadIdx.x == 0) carry = c + tot;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) start[nbins] = carry;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Join task list.  The loop of Result.cpp:98-107 schedules one JoinJob per bucket with both sides
+// non-empty; here a partition whose probe side is longer than probe_split is cut into several tasks
+// (probe-side load balance under skew).  Build side = S when |R_k| >= |S_k| (JobScheduler.cpp:187).
+// One atomic per workgroup reserves its tasks' slots.
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(1024)
+k_make_tasks(const u64 *__restrict__ startR, const u64 *__restrict__ startS, u64 nparts, u32 probe_split,
+             JoinTask *__restrict__ tasks, u32 *__restrict__ ntasks, u32 max_tasks)
+{
+    __shared__ u32 wsum[16];
+    __shared__ u32 gbase;
+    const u64 k = (u64)blockIdx.x * 1024 + threadIdx.x;
+    u32 nt = 0;
+    u64 pbeg = 0, plen = 0;
+    if (k < nparts) {
+        const u64 r0 = startR[k], nr = startR[k + 1] - r0, s0 = startS[k], ns = startS[k + 1] - s0;
+        if (nr != 0 && ns != 0) {
+            if (nr >= ns) { pbeg = r0; plen = nr; } else { pbeg = s0; plen = ns; }
+            nt = (u32)((plen + probe_split - 1) / probe_split);
+        }
+    }
+    u32 tot;
+    const u32 ex = block_excl_scan<1024>(nt, wsum, tot);
+    if (threadIdx.x == 0) gbase = tot ? atomicAdd(ntasks, tot) : 0u;
+    __syncthreads();
+    u32 slot = gbase + ex;
+    for (u32 j = 0; j < nt; j++, slot++) {
+        if (slot >= max_tasks) break;                  // cannot happen: max_tasks is an upper bound
+        JoinTask t;
+        t.pbeg = pbeg + (u64)j * probe_split;
+        const u64 rem = plen - (u64)j * probe_split;
+        t.plen = (u32)(rem < probe_split ? rem : probe_split);
+        t.part = (u32)k;
+        tasks[slot] = t;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// K4: bucket build + probe + result write.  JoinJob::run + Result::join_buckets (Result.cpp:43-76)
+// with the page appends of add_result/addAll (Result.cpp:21-35, 78-84, 111-121) replaced by a
+// count -> workgroup scan -> one global reservation -> coalesced 16 B pair stores.
+//   build:  LDS chained hash table over a chunk of <= JOIN_CHUNK tuples of the smaller side:
+//           head[h] <- i (LDS atomic exchange), next[i] <- previous head   (Result.cpp:54-58)
+//   probe:  per probe tuple walk the chain with full 64-bit compares       (Result.cpp:61-73)
+// The hash is Fibonacci hashing of the payload bits above the radix bits (those below are equal
+// inside a partition); the result set does not depend on it (full-key equality test).
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ u32 hash_slot(u64 v, int radix_bits)
+{
+    return (u32)(((v >> radix_bits) * 0x9E3779B97F4A7C15ULL) >> (64 - 13));   // JOIN_HEADS = 2^13
+}
+static_assert(JOIN_HEADS == (1 << 13), "hash_slot assumes 8192 heads");
+static_assert(JOIN_CHUNK < 65535, "next[] is 16-bit");
+
+__global__ void __launch_bounds__(JOIN_THREADS)
+k_join(const Tup *__restrict__ R, const u64 *__restrict__ startR, const Tup *__restrict__ S,
+       const u64 *__restrict__ startS, const JoinTask *__restrict__ tasks, const u32 *__restrict__ ntasks,
+       int radix_bits, Pair *__restrict__ out, u64 out_capacity, u64 *__restrict__ out_count)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    u64 *keys = reinterpret_cast<u64 *>(smem);                       // JOIN_CHUNK * 8
+    u64 *rids = keys + JOIN_CHUNK;                                   // JOIN_CHUNK * 8
+    u32 *head = reinterpret_cast<u32 *>(rids + JOIN_CHUNK);          // JOIN_HEADS * 4   (index+1, 0 = empty)
+    unsigned short *next = reinterpret_cast<unsigned short *>(head + JOIN_HEADS);  // JOIN_CHUNK * 2
+    u32 (*wsum)[JOIN_THREADS / 64] = reinterpret_cast<u32 (*)[JOIN_THREADS / 64]>(next + JOIN_CHUNK);  // EPT*16*4
+    u64 *gres_p = reinterpret_cast<u64 *>(&wsum[JOIN_EPT][0]);
+
+    if (blockIdx.x >= *ntasks) return;
+    const JoinTask task = tasks[blockIdx.x];
+    const u64 r0 = startR[task.part], nr = startR[task.part + 1] - r0;
+    const u64 s0 = startS[task.part], ns = startS[task.part + 1] - s0;
+    const bool build_is_S = (nr >= ns);                              // JobScheduler.cpp:187
+    const Tup *__restrict__ B = build_is_S ? S + s0 : R + r0;
+    const u64 nb = build_is_S ? ns : nr;
+    const Tup *__restrict__ P = (build_is_S ? R : S) + task.pbeg;
+    const u32 np = task.plen;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+
+    for (u64 cb = 0; cb < nb; cb += JOIN_CHUNK) {
+        const u32 nc = (nb - cb < (u64)JOIN_CHUNK) ? (u32)(nb - cb) : (u32)JOIN_CHUNK;
+        for (u32 h = tid; h < JOIN_HEADS; h += JOIN_THREADS) head[h] = 0;
+        __syncthreads();
+        for (u32 i = tid; i < nc; i += JOIN_THREADS) {
+            const Tup t = B[cb + i];
+            keys[i] = t.payload;
+            rids[i] = t.key;
+            const u32 old = atomicExch(&head[hash_slot(t.payload, radix_bits)], i + 1);
+            next[i] = (unsigned short)old;
+        }
+        __syncthreads();
+
+        for (u32 tb = 0; tb < np; tb += JOIN_TILE) {
+            Tup p[JOIN_EPT];
+            u32 cnt[JOIN_EPT], first[JOIN_EPT];
+#pragma unroll
+            for (int k = 0; k < JOIN_EPT; k++) {
+                const u32 i = tb + k * JOIN_THREADS + tid;
+                cnt[k] = 0; first[k] = 0;
+                if (i < np) p[k] = P[i];
+            }
+#pragma unroll
+            for (int k = 0; k < JOIN_EPT; k++) {
+                const u32 i = tb + k * JOIN_THREADS + tid;
+                if (i < np) {
+                    u32 j = head[hash_slot(p[k].payload, radix_bits)];
+                    while (j) {
+                        if (keys[j - 1] == p[k].payload) { if (!cnt[k]) first[k] = j; cnt[k]++; }
+                        j = next[j - 1];
+                    }
+                }
+            }
+            // JOIN_EPT simultaneous workgroup scans (slot-major output order => consecutive lanes write
+            // consecutive pairs when each probe tuple has one match)
+            u32 inc[JOIN_EPT];
+#pragma unroll
+            for (int k = 0; k < JOIN_EPT; k++) inc[k] = cnt[k];
+#pragma unroll
+            for (int off = 1; off < 64; off <<= 1) {
+#pragma unroll
+                for (int k = 0; k < JOIN_EPT; k++) {
+                    const u32 t = __shfl_up(inc[k], off, 64);
+                    if (lane >= off) inc[k] += t;
+                }
+            }
+            if (lane == 63) {
+#pragma unroll
+                for (int k = 0; k < JOIN_EPT; k++) wsum[k][w] = inc[k];
+            }
+            __syncthreads();
+            u64 slot_base[JOIN_EPT];
+            u64 tile_total = 0;
+#pragma unroll
+            for (int k = 0; k < JOIN_EPT; k++) {
+                u32 pre = 0, tot = 0;
+#pragma unroll
+                for (int i = 0; i < JOIN_THREADS / 64; i++) { const u32 x = wsum[k][i]; if (i < w) pre += x; tot += x; }
+                slot_base[k] = tile_total + pre + inc[k] - cnt[k];
+                tile_total += tot;
+            }
+            if (tid == 0 && tile_total) *gres_p = atomicAdd(out_count, tile_total);
+            __syncthreads();
+            if (tile_total && out != nullptr) {
+                const u64 g = *gres_p;
+#pragma unroll
+                for (int k = 0; k < JOIN_EPT; k++) {
+                    if (cnt[k] == 0) continue;
+                    u64 o = g + slot_base[k];
+                    u32 j = first[k];
+                    u32 left = cnt[k];
+                    while (left) {                       // first[k] is the first match: at most cnt[k] hops matter
+                        if (keys[j - 1] == p[k].payload) {
+                            if (o < out_capacity) {
+                                Pair pr;
+                                if (build_is_S) { pr.r = p[k].key; pr.s = rids[j - 1]; }   // orderFlag, Result.cpp:64-68
+                                else            { pr.r = rids[j - 1]; pr.s = p[k].key; }
+                                out[o] = pr;
+                            }
+                            o++; left--;
+                        }
+                        j = next[j - 1];
+                    }
+                }
+            }
+            __syncthreads();     // gres_p / wsum reuse
+        }
+        __syncthreads();         // table reuse by the next build chunk
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// utilities
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ u64 block_sum_u64(u64 v, u64 *wtot)
+{
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+    if ((threadIdx.x & 63) == 0) wtot[threadIdx.x >> 6] = v;
+    __syncthreads();
+    u64 t = 0;
+    if (threadIdx.x == 0) for (int i = 0; i < (int)(blockDim.x >> 6); i++) t += wtot[i];
+    return t;
+}
+
+__global__ void __launch_bounds__(256) k_checksum(const Pair *__restrict__ p, u64 n, u64 *__restrict__ sum)
+{
+    __shared__ u64 wtot[4];
+    u64 acc = 0;
+    for (u64 i = (u64)blockIdx.x * 256 + threadIdx.x; i < n; i += (u64)gridDim.x * 256) {
+        const Pair x = p[i];
+        acc += mix64(x.r * 0x100000001B3ULL ^ mix64(x.s));
+    }
+    const u64 t = block_sum_u64(acc, wtot);
+    if (threadIdx.x == 0) atomicAdd(sum, t);
+}
+
+__global__ void __launch_bounds__(256) k_expected_pkfk(const Tup *__restrict__ S, u64 n, u64 *__restrict__ sum)
+{
+    __shared__ u64 wtot[4];
+    u64 acc = 0;
+    for (u64 i = (u64)blockIdx.x * 256 + threadIdx.x; i < n; i += (u64)gridDim.x * 256) {
+        const Tup x = S[i];
+        const u64 k = unmix64(x.payload);              // payload = mix(k), R row = k - 1
+        acc += mix64((k - 1) * 0x100000001B3ULL ^ mix64(x.key));
+    }
+    const u64 t = block_sum_u64(acc, wtot);
+    if (threadIdx.x == 0) atomicAdd(sum, t);
+}
+
+__global__ void __launch_bounds__(256)
+k_generate(int kind, Tup *__restrict__ out, u64 n, u64 row0, u64 D, u64 seed, double theta)
+{
+    const double e = 1.0 - theta;
+    const double span = (kind == 2) ? (pow((double)D + 1.0, e) - 1.0) : 0.0;
+    for (u64 i = (u64)blockIdx.x * 256 + threadIdx.x; i < n; i += (u64)gridDim.x * 256) {
+        const u64 row = row0 + i;
+        Tup t;
+        t.key = row;
+        switch (kind) {
+        case 0: t.payload = mix64(1 + row % D); break;
+        case 1: t.payload = mix64(1 + mix64(row ^ seed) % D); break;
+        case 2: {
+            const double uu = (double)(mix64(row ^ seed) >> 11) * (1.0 / 9007199254740992.0);   // [0,1)
+            double x = pow(1.0 + uu * span, 1.0 / e);
+            u64 r = (u64)x;
+            if (r < 1) r = 1;
+            if (r > D) r = D;
+            t.payload = mix64(r);
+            break;
+        }
+        case 3: t.payload = mix64(D + 1 + row); break;
+        default: t.payload = D; break;
+        }
+        out[i] = t;
+    }
+}
+
+}  // namespace
+
+// ------------------------------------------------------------------------------------------------
+// launchers
+// ------------------------------------------------------------------------------------------------
+size_t part_lds_bytes(int bits)
+{
+    const size_t nbins = (size_t)1 << bits;
+    return (size_t)PART_TILE * 16 + nbins * (8 + 4 + 4) + (PART_THREADS / 64) * 4;
+}
+
+size_t join_lds_bytes()
+{
+    return (size_t)JOIN_CHUNK * 16 + (size_t)JOIN_HEADS * 4 + (size_t)JOIN_CHUNK * 2 +
+           (size_t)JOIN_EPT * (JOIN_THREADS / 64) * 4 + 16;
+}
+
+static void allow_big_lds()
+{
+    static bool done = false;
+    if (done) return;
+    done = true;
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_scatter_units),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)part_lds_bytes(PART_MAX_BITS));
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_join),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)join_lds_bytes());
+}
+
+void launch_init_single_segment(hipStream_t st, u64 n, u64 L, u64 *d_seg_start, u32 *d_unit_start)
+{
+    hipLaunchKernelGGL(k_init_single_segment, dim3(1), dim3(64), 0, st, n, L, d_seg_start, d_unit_start);
+}
+
+void launch_make_units(hipStream_t st, const u64 *d_seg_start, u32 nseg, u64 L, u32 *d_unit_start)
+{
+    hipLaunchKernelGGL(k_make_units, dim3(1), dim3(1024), 0, st, d_seg_start, nseg, L, d_unit_start);
+}
+
+void launch_hist_units(hipStream_t st, const void *d_in, const PassGeom &g, const u64 *d_seg_start,
+                       const u32 *d_unit_start, u32 *d_unit_hist)
+{
+    if (g.max_units == 0) return;
+    hipLaunchKernelGGL(k_hist_units, dim3(g.max_units), dim3(PART_THREADS), ((size_t)4 << g.bits), st,
+                       (const Tup *)d_in, d_seg_start, d_unit_start, g.nseg, g.L, g.shift, g.bits, d_unit_hist);
+}
+
+void launch_scan_units(hipStream_t st, const PassGeom &g, const u64 *d_seg_start, const u32 *d_unit_start,
+                       const u32 *d_unit_hist, u64 *d_unit_base, u64 *d_part_start)
+{
+    const size_t nbins = (size_t)1 << g.bits;
+    const size_t G = 1024 / nbins;
+    hipLaunchKernelGGL(k_scan_units, dim3(g.nseg), dim3(1024), G * nbins * 4, st, d_seg_start, d_unit_start,
+                       g.nseg, g.bits, d_unit_hist, d_unit_base, d_part_start, g.n);
+}
+
+void launch_scatter_units(hipStream_t st, const void *d_in, void *d_out, const PassGeom &g,
+                          const u64 *d_seg_start, const u32 *d_unit_start, const u64 *d_unit_base)
+{
+    if (g.max_units == 0) return;
+    allow_big_lds();
+    hipLaunchKernelGGL(k_scatter_units, dim3(g.max_units), dim3(PART_THREADS), part_lds_bytes(g.bits), st,
+                       (const Tup *)d_in, (Tup *)d_out, d_seg_start, d_unit_start, g.nseg, g.L, g.shift, g.bits,
+                       d_unit_base);
+}
+
+void launch_diff_hist(hipStream_t st, const u64 *d_start, u64 nbins, u64 *d_hist)
+{
+    hipLaunchKernelGGL(k_diff_hist, dim3((unsigned)((nbins + 255) / 256)), dim3(256), 0, st, d_start, nbins, d_hist);
+}
+
+void launch_prefix(hipStream_t st, const u64 *d_hist, u64 nbins, u64 *d_start)
+{
+    hipLaunchKernelGGL(k_prefix, dim3(1), dim3(1024), 0, st, d_hist, nbins, d_start);
+}
+
+void launch_make_tasks(hipStream_t st, const u64 *d_startR, const u64 *d_startS, u64 nparts, u32 probe_split,
+                       JoinTask *d_tasks, u32 *d_ntasks, u32 max_tasks)
+{
+    hipLaunchKernelGGL(k_make_tasks, dim3((unsigned)((nparts + 1023) / 1024)), dim3(1024), 0, st, d_startR, d_startS,
+                       nparts, probe_split, d_tasks, d_ntasks, max_tasks);
+}
+
+void launch_join(hipStream_t st, const void *d_R, const u64 *d_startR, const void *d_S, const u64 *d_startS,
+                 const JoinTask *d_tasks, const u32 *d_ntasks, u32 grid, int radix_bits,
+                 void *d_out, u64 out_capacity, u64 *d_out_count)
+{
+    if (grid == 0) return;
+    allow_big_lds();
+    hipLaunchKernelGGL(k_join, dim3(grid), dim3(JOIN_THREADS), join_lds_bytes(), st, (const Tup *)d_R, d_startR,
+                       (const Tup *)d_S, d_startS, d_tasks, d_ntasks, radix_bits, (Pair *)d_out, out_capacity,
+                       d_out_count);
+}
+
+static unsigned stream_grid(u64 n)
+{
+    u64 g = (n + 255) / 256;
+    if (g > 4096) g = 4096;
+    if (g == 0) g = 1;
+    return (unsigned)g;
+}
+
+void launch_checksum(hipStream_t st, const void *d_pairs, u64 n, u64 *d_sum)
+{
+    hipLaunchKernelGGL(k_checksum, dim3(stream_grid(n)), dim3(256), 0, st, (const Pair *)d_pairs, n, d_sum);
+}
+
+void launch_expected_pkfk(hipStream_t st, const void *d_S, u64 n, u64 *d_sum)
+{
+    hipLaunchKernelGGL(k_expected_pkfk, dim3(stream_grid(n)), dim3(256), 0, st, (const Tup *)d_S, n, d_sum);
+}
+
+void launch_generate(hipStream_t st, int kind, void *d_out, u64 n, u64 row0, u64 D, u64 seed, double theta)
+{
+    hipLaunchKernelGGL(k_generate, dim3(stream_grid(n)), dim3(256), 0, st, kind, (Tup *)d_out, n, row0, D, seed, theta);
+}

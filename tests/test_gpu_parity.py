@@ -1,0 +1,301 @@
+"""GPU suite (pytest -m gpu): the HIP path, called through the C-ABI, against the CPU oracle, the
+committed golden fixtures of the real reference, and size-independent properties at large sizes.
+Bar: bit-exact pair multisets (order-insensitive), bit-exact histograms / partition boundaries."""
+import numpy as np
+import pytest
+
+from conftest import make_inputs, small_call_arrays
+from oracle.pyoracle import PAIR, TUPLE, sorted_pairs
+from radixhashjoin_amd import Opts, RhjError
+from radixhashjoin_amd.binding import GEN_CONST, GEN_R, GEN_S_DISJOINT, GEN_S_UNIFORM, GEN_S_ZIPF, RHJ_E_OVERFLOW
+
+pytestmark = pytest.mark.gpu
+
+GOLDEN_CASES = ["pkfk_1k", "pkfk_1m", "pkfk_16m", "pkfk_4m_x_1m", "pkfk_300k_x_3m", "dup_10k", "dup_100k_50k",
+                "dup_2m_d64k", "alleq_300_500", "alleq_7000_9", "tinyR_1_1000", "tinyS_1000_1", "tiny_5_3",
+                "lt_ranges_7_7", "one_one", "disjoint_1k", "disjoint_200k", "chunk_edge_6144", "chunk_edge_6145",
+                "small_build_big_probe"]
+
+
+def rand_rel(rng, n, dom, key0=0):
+    t = np.empty(n, dtype=TUPLE)
+    t["key"] = rng.permutation(n) + key0
+    t["payload"] = rng.integers(0, dom, n, dtype=np.uint64)
+    return t
+
+
+# ---------------------------------------------------------------------------------------------------
+# the drop-in entry point (host arrays in, result page out): golden vectors of the real reference
+# ---------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("name", GOLDEN_CASES)
+def test_join_golden(engine, oracle, synthetic_golden, name):
+    g = synthetic_golden[name]
+    R, S = make_inputs(oracle, g["spec"])
+    pairs = engine.join(R, S)
+    assert len(pairs) == g["count"]
+    assert f"{oracle.pairs_checksum(pairs):016x}" == g["checksum"]
+    if len(pairs) <= 5_000_000 and len(R) + len(S) <= 4_000_000:
+        assert np.array_equal(sorted_pairs(pairs), sorted_pairs(oracle.join(R, S)))
+
+
+def test_join_golden_64m(engine, oracle, synthetic_golden):
+    g = synthetic_golden["pkfk_64m"]                    # known answer recorded from the real reference
+    R, S = make_inputs(oracle, g["spec"])
+    pairs = engine.join(R, S)
+    assert len(pairs) == g["count"]
+    assert f"{oracle.pairs_checksum(pairs):016x}" == g["checksum"]
+
+
+def test_tiny_vectors(engine, tiny_vectors):
+    for n in sorted({k.split("__")[0] for k in tiny_vectors.files}):
+        R, S, P = tiny_vectors[n + "__R"], tiny_vectors[n + "__S"], tiny_vectors[n + "__pairs"]
+        got = engine.join(R.astype(TUPLE), S.astype(TUPLE))
+        assert np.array_equal(sorted_pairs(got), sorted_pairs(P.astype(PAIR))), n
+
+
+def test_small_work_calls(engine, oracle, small_joins):
+    """the joins the reference itself performs on small/small.work (link-time tap fixtures)"""
+    meta, npz = small_joins
+    full = [i for i, c in enumerate(meta) if c.get("vectors")]
+    assert len(full) >= 10
+    for i in full:
+        R, S, P = small_call_arrays(npz, i)
+        got = engine.join(R, S)
+        assert len(got) == meta[i]["count"]
+        assert f"{oracle.pairs_checksum(got):016x}" == meta[i]["checksum"]
+        assert np.array_equal(sorted_pairs(got), sorted_pairs(P))
+
+
+def test_empty_inputs(engine, oracle):
+    R = oracle.gen_R(100)
+    E = np.empty(0, dtype=TUPLE)
+    assert len(engine.join(E, R)) == 0 and len(engine.join(R, E)) == 0 and len(engine.join(E, E)) == 0
+
+
+def test_random_joins_vs_oracle(engine, oracle):
+    rng = np.random.default_rng(11)
+    for trial in range(60):
+        sizes_r, sizes_s = [1, 2, 63, 64, 65, 1000, 5000, 20000, 70000], [1, 3, 64, 1023, 4097, 30000, 90000]
+        doms = [1, 2, 17, 300, 5000, 1 << 18, 1 << 33, (1 << 64) - 1]
+        nR, nS = sizes_r[int(rng.integers(len(sizes_r)))], sizes_s[int(rng.integers(len(sizes_s)))]
+        dom = doms[int(rng.integers(len(doms)))]
+        if dom <= 17 and nR * nS > 4_000_000:
+            dom = 5000
+        R, S = rand_rel(rng, nR, dom), rand_rel(rng, nS, dom, key0=10**6)
+        got = engine.join(R, S)
+        exp = oracle.join(R, S)
+        assert len(got) == len(exp), (nR, nS, dom)
+        assert np.array_equal(sorted_pairs(got), sorted_pairs(exp)), (nR, nS, dom)
+
+
+def test_full_width_rowids_and_values(engine, oracle):
+    rng = np.random.default_rng(5)
+    n = 30000
+    R = np.empty(n, dtype=TUPLE); S = np.empty(n, dtype=TUPLE)
+    R["key"] = rng.integers(0, 1 << 64, n, dtype=np.uint64); S["key"] = rng.integers(0, 1 << 64, n, dtype=np.uint64)
+    vals = rng.integers(0, 1 << 64, n // 2, dtype=np.uint64)
+    R["payload"] = vals[rng.integers(0, len(vals), n)]; S["payload"] = vals[rng.integers(0, len(vals), n)]
+    R["payload"][:10] = [0, 1, (1 << 64) - 1, 1 << 63, 255, 256, 65535, 65536, 1 << 32, (1 << 32) - 1]
+    S["payload"][:10] = R["payload"][:10]
+    assert np.array_equal(sorted_pairs(engine.join(R, S)), sorted_pairs(oracle.join(R, S)))
+
+
+# ---------------------------------------------------------------------------------------------------
+# the result does not depend on the radix plan (full 64-bit equality test)
+# ---------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("plan", [Opts(0), Opts(1, 1), Opts(1, 4), Opts(1, 8), Opts(1, 10), Opts(2, 1, 1), Opts(2, 3, 5),
+                                  Opts(2, 8, 8), Opts(2, 10, 10), Opts(2, 8, 8, 4096), Opts(0, 0, 0, 4096)])
+def test_plan_independence(engine, oracle, plan):
+    R, S = oracle.gen_R(200_000, 50_000), oracle.gen_S_chain(300_000, 50_000)    # 4 copies of each value in R
+    exp_n, exp_c = oracle.join_count_checksum(R, S)
+    got = engine.join(R, S, opts=plan)
+    assert (len(got), oracle.pairs_checksum(got)) == (exp_n, exp_c)
+
+
+def test_build_side_larger_than_lds_table(engine, oracle):
+    # passes=0 with a 20k-tuple build side: the bucket join must chunk the build side (3.3 LDS tables)
+    R, S = oracle.gen_R(20_000, 15_000), oracle.gen_S_chain(50_000, 15_000)
+    got = engine.join(R, S, opts=Opts(0))
+    assert np.array_equal(sorted_pairs(got), sorted_pairs(oracle.join(R, S)))
+
+
+def test_skewed_probe_side(engine, oracle):
+    # one hot key holds 60 % of S: its partition is cut into many probe tasks
+    rng = np.random.default_rng(3)
+    R = oracle.gen_R(100_000)
+    S = oracle.gen_S_chain(400_000, 100_000)
+    hot = rng.random(len(S)) < 0.6
+    S["payload"][hot] = R["payload"][777]
+    got = engine.join(R, S)
+    exp_n, exp_c = oracle.join_count_checksum(R, S)
+    assert (len(got), oracle.pairs_checksum(got)) == (exp_n, exp_c)
+    assert int((got["keyR"] == 777).sum()) >= int(hot.sum())
+
+
+# ---------------------------------------------------------------------------------------------------
+# stage entry points: histogram / prefix / partition / bucket_join
+# ---------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("n,shift,bits", [(0, 0, 8), (1, 0, 8), (4095, 0, 8), (4096, 0, 8), (4097, 3, 5), (1_000_003, 0, 8),
+                                          (1_000_003, 8, 8), (3_000_000, 0, 10), (10_000_000, 56, 8), (777_777, 0, 1)])
+def test_histogram_bit_exact(engine, oracle, n, shift, bits):
+    R = oracle.gen_R(n, max(n // 2, 1))
+    dR = engine.to_device(R)
+    dH = engine.alloc(8 << bits)
+    engine.histogram(dR, n, shift, bits, dH)
+    got = dH.to_numpy(np.uint64, 1 << bits)
+    exp = np.bincount(((R["payload"] >> np.uint64(shift)) & np.uint64((1 << bits) - 1)).astype(np.int64), minlength=1 << bits)
+    assert np.array_equal(got, exp.astype(np.uint64))
+    if shift == 0 and bits == 8 and n:
+        _, h = oracle.hash_relation(R)                      # HistogramJob + reduce of the reference algorithm
+        assert np.array_equal(got, h)
+
+
+@pytest.mark.parametrize("nbins", [1, 2, 255, 256, 1024, 1025, 65536, 100_000])
+def test_prefix_bit_exact(engine, nbins):
+    rng = np.random.default_rng(nbins)
+    h = rng.integers(0, 1 << 40, nbins, dtype=np.uint64)
+    dH, dS = engine.to_device(h), engine.alloc(8 * (nbins + 1))
+    engine.prefix(dH, nbins, dS)
+    got = dS.to_numpy(np.uint64, nbins + 1)
+    assert got[0] == 0 and np.array_equal(got[1:], np.cumsum(h, dtype=np.uint64))
+
+
+def check_partition(R, out, ps, bits1, bits2):
+    n = len(R)
+    tb = bits1 + bits2
+    p = (R["payload"] & np.uint64((1 << tb) - 1)).astype(np.int64)
+    order_id = ((p & ((1 << bits1) - 1)) << bits2) | (p >> bits1)        # layout order documented in rhj.h
+    cnt = np.bincount(order_id, minlength=1 << tb)
+    exp_ps = np.concatenate([[0], np.cumsum(cnt)]).astype(np.uint64)
+    assert np.array_equal(ps, exp_ps)
+    po = (out["payload"] & np.uint64((1 << tb) - 1)).astype(np.int64)
+    oid = ((po & ((1 << bits1) - 1)) << bits2) | (po >> bits1)
+    assert np.all(np.diff(oid) >= 0)                                      # grouped, in layout order
+    # same multiset of tuples inside every partition: sort both by (partition, rowID)
+    a = out[np.lexsort((out["key"], oid))]
+    b = R[np.lexsort((R["key"], order_id))]
+    assert np.array_equal(a, b)
+    assert len(out) == n
+
+
+@pytest.mark.parametrize("n,bits1,bits2", [(1, 8, 0), (100, 8, 0), (4096, 8, 0), (4097, 8, 0), (1_000_000, 8, 0),
+                                           (1_000_000, 1, 0), (1_000_000, 10, 0), (3_000_001, 8, 8), (2_000_000, 3, 10),
+                                           (5_000_000, 9, 9), (300_000, 10, 10)])
+def test_partition_bit_exact(engine, oracle, n, bits1, bits2):
+    R = oracle.gen_R(n, max(n // 2, 1))
+    dR, dO = engine.to_device(R), engine.alloc(16 * n)
+    nparts = 1 << (bits1 + bits2)
+    dP = engine.alloc(8 * (nparts + 1))
+    engine.partition(dR, n, bits1, bits2, dO, dP)
+    out, ps = dO.to_numpy(TUPLE, n), dP.to_numpy(np.uint64, nparts + 1)
+    check_partition(R, out, ps, bits1, bits2)
+    if (bits1, bits2) == (8, 0):
+        # the reference's R' (stable) holds the same tuples per bucket, and the same histogram
+        ref_out, h = oracle.hash_relation(R)
+        assert np.array_equal(np.diff(ps.astype(np.int64)), h.astype(np.int64))
+        d = (out["payload"] & np.uint64(255)).astype(np.int64)
+        assert np.array_equal(out[np.lexsort((out["key"], d))], ref_out[np.lexsort((ref_out["key"], (ref_out["payload"] & np.uint64(255)).astype(np.int64)))])
+
+
+def test_partition_skewed_digits(engine, oracle):
+    n = 1_500_000
+    R = oracle.gen_R(n)
+    R["payload"][: n // 2] = 0xABCDEF                 # half of the tuples in one partition
+    R["payload"][n // 2: n // 2 + 1000] &= np.uint64(~0xFF & ((1 << 64) - 1))
+    dR, dO, dP = engine.to_device(R), engine.alloc(16 * n), engine.alloc(8 * 65537)
+    engine.partition(dR, n, 8, 8, dO, dP)
+    check_partition(R, dO.to_numpy(TUPLE, n), dP.to_numpy(np.uint64, 65537), 8, 8)
+
+
+def test_bucket_join_on_reference_partitions(engine, oracle):
+    """JoinJob stage alone, fed with the oracle's own R', S' (hash_relation of the reference algorithm)."""
+    R, S = oracle.gen_R(300_000, 100_000), oracle.gen_S_chain(200_000, 100_000)
+    Rp, hR = oracle.hash_relation(R)
+    Sp, hS = oracle.hash_relation(S)
+    sR = np.concatenate([[0], np.cumsum(hR)]).astype(np.uint64)
+    sS = np.concatenate([[0], np.cumsum(hS)]).astype(np.uint64)
+    exp = oracle.join(R, S)
+    dRp, dSp, dsR, dsS = engine.to_device(Rp), engine.to_device(Sp), engine.to_device(sR), engine.to_device(sS)
+    n = engine.bucket_join(dRp, dsR, dSp, dsS, 256, 8)                     # count only
+    assert n == len(exp)
+    dO = engine.alloc(16 * n)
+    n2 = engine.bucket_join(dRp, dsR, dSp, dsS, 256, 8, dO, n)
+    assert n2 == n
+    assert np.array_equal(sorted_pairs(dO.to_numpy(PAIR, n)), sorted_pairs(exp))
+
+
+def test_overflow_and_count_only(engine, oracle):
+    R, S = oracle.gen_R(10_000, 100), oracle.gen_S_chain(10_000, 100)      # 1,000,000 pairs
+    dR, dS = engine.to_device(R), engine.to_device(S)
+    assert engine.join_dev(dR, len(R), dS, len(S)) == 1_000_000            # count only
+    dO = engine.alloc(16 * 1000)
+    with pytest.raises(RhjError) as e:
+        engine.join_dev(dR, len(R), dS, len(S), dO, 1000)
+    assert e.value.code == RHJ_E_OVERFLOW
+    assert engine.join_dev(dR, len(R), dS, len(S), dO, 1000, allow_overflow=True) == 1_000_000
+    part = dO.to_numpy(PAIR, 1000)                                          # what was written is still valid pairs
+    assert np.all(R["payload"][part["keyR"]] == S["payload"][part["keyS"]])
+    dO2 = engine.alloc(16 * 1_000_000)
+    assert engine.join_dev(dR, len(R), dS, len(S), dO2, 1_000_000) == 1_000_000
+    assert engine.pairs_checksum(dO2, 1_000_000) == oracle.pairs_checksum(oracle.join(R, S))
+
+
+def test_inputs_not_modified(engine, oracle):
+    R, S = oracle.gen_R(500_000), oracle.gen_S_chain(500_000, 500_000)
+    dR, dS = engine.to_device(R), engine.to_device(S)
+    engine.join_dev(dR, len(R), dS, len(S), opts=Opts(2, 8, 8))
+    assert np.array_equal(dR.to_numpy(TUPLE, len(R)), R) and np.array_equal(dS.to_numpy(TUPLE, len(S)), S)
+
+
+# ---------------------------------------------------------------------------------------------------
+# device generators + closed-form expectation (used at BASELINE sizes where the CPU oracle cannot run)
+# ---------------------------------------------------------------------------------------------------
+def test_device_generators_match_oracle(engine, oracle):
+    n, D = 100_000, 30_000
+    d = engine.alloc(16 * n)
+    engine.generate(GEN_R, d, n, 0, D)
+    assert np.array_equal(d.to_numpy(TUPLE, n), oracle.gen_R(n, D))
+    engine.generate(GEN_S_UNIFORM, d, n, 0, D, seed=42)
+    assert np.array_equal(d.to_numpy(TUPLE, n), oracle.gen_S_counter(n, D, 42))
+    engine.generate(GEN_S_DISJOINT, d, n, 0, D)
+    assert np.array_equal(d.to_numpy(TUPLE, n), oracle.gen_S_disjoint(n, D))
+    engine.generate(GEN_CONST, d, n, 0, 7)
+    assert np.array_equal(d.to_numpy(TUPLE, n), oracle.gen_const(n, 7))
+    engine.generate(GEN_R, d, 1000, 5000, D)                                # row0 offset (range shards)
+    assert np.array_equal(d.to_numpy(TUPLE, 1000), oracle.gen_R(6000, D)[5000:])
+
+
+@pytest.mark.parametrize("kind,theta", [(GEN_S_UNIFORM, 0), (GEN_S_ZIPF, 900)])
+def test_expected_pkfk_matches_oracle_join(engine, oracle, kind, theta):
+    nR, nS = 2_000_000, 3_000_000
+    dR, dS = engine.alloc(16 * nR), engine.alloc(16 * nS)
+    engine.generate(GEN_R, dR, nR, 0, nR)
+    engine.generate(kind, dS, nS, 0, nR, seed=42, theta_milli=theta)
+    S = dS.to_numpy(TUPLE, nS)
+    exp_n, exp_c = oracle.join_count_checksum(oracle.gen_R(nR), S)         # the oracle, on the device-made S
+    cnt, chk = engine.expected_pkfk(dS, nS)
+    assert (cnt, chk) == (exp_n, exp_c) == (nS, chk)
+    dO = engine.alloc(16 * nS)
+    assert engine.join_dev(dR, nR, dS, nS, dO, nS) == nS
+    assert engine.pairs_checksum(dO, nS) == exp_c
+    if kind == GEN_S_ZIPF:
+        top = np.bincount((S["payload"] == oracle.mix(1)).astype(np.int64))[1] / nS
+        assert 0.005 < top < 0.05                                           # hottest key holds ~1-2 % of S
+
+
+@pytest.mark.parametrize("n,plan,kind", [(64_000_000, Opts(), GEN_S_UNIFORM), (256_000_000, Opts(2, 8, 8), GEN_S_UNIFORM),
+                                         (256_000_000, Opts(), GEN_S_ZIPF)])
+def test_large_device_resident(engine, n, plan, kind):
+    """size-independent properties at sizes the CPU oracle cannot reach inside a test:
+    exact count, checksum of the pair set == closed form, every emitted pair joins equal values."""
+    free, _ = engine.mem_info()
+    if free < 16 * n * 7:
+        pytest.skip("not enough free HBM")
+    dR, dS, dO = engine.alloc(16 * n), engine.alloc(16 * n), engine.alloc(16 * n)
+    engine.generate(GEN_R, dR, n, 0, n)
+    engine.generate(kind, dS, n, 0, n, seed=1234, theta_milli=900)
+    exp_n, exp_c = engine.expected_pkfk(dS, n)
+    got = engine.join_dev(dR, n, dS, n, dO, n, opts=plan)
+    assert got == exp_n == n
+    assert engine.pairs_checksum(dO, n) == exp_c
+    engine.release_workspace()

@@ -1,0 +1,76 @@
+#!/usr/bin/env python3
+"""profiles/summarize.py <tag> [round]: condense gpurun_out/prof_<tag>/ (written by run_profile.sh)
+into tracked files under profiles/:
+  <round>_<tag>_kernel_stats.csv   rocprofv3 --kernel-trace --stats summary, kernel names shortened
+  <round>_<tag>_pmc.json           per-kernel average FETCH_SIZE / WRITE_SIZE per launch and the HBM
+                                   bytes derived as MI355X_MICROARCH.md §HBM prescribes:
+                                   FETCH_SIZE, WRITE_SIZE are in KiB; on gfx950 FETCH_SIZE reports
+                                   half of the bytes of a wide (16 B/lane) coalesced streaming read,
+                                   so read bytes = 2 * FETCH_SIZE * 1024 for the streaming kernels here.
+  traffic.json                     what bench.py reports as roofline.traffic (scatter kernel, per launch)
+"""
+import csv
+import glob
+import json
+import os
+import re
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+tag = sys.argv[1]
+rnd = sys.argv[2] if len(sys.argv) > 2 else "r01"
+src = os.path.join(ROOT, "gpurun_out", f"prof_{tag}")
+
+
+def short(name):
+    m = re.search(r"(k_[a-z_0-9]+|__amd_rocclr_[A-Za-z]+)", name)
+    return m.group(1) if m else name[:40]
+
+
+stats = glob.glob(os.path.join(src, "trace", "*", "*_kernel_stats.csv"))[0]
+rows = list(csv.DictReader(open(stats)))
+with open(os.path.join(ROOT, "profiles", f"{rnd}_{tag}_kernel_stats.csv"), "w") as f:
+    w = csv.writer(f)
+    w.writerow(["Name", "Calls", "TotalDurationNs", "AverageNs", "Percentage", "MinNs", "MaxNs"])
+    for r in rows:
+        w.writerow([short(r["Name"]), r["Calls"], r["TotalDurationNs"], r["AverageNs"], r["Percentage"], r["MinNs"], r["MaxNs"]])
+
+pmc = {}
+for counter, d in (("FETCH_SIZE", "pmc_fetch"), ("WRITE_SIZE", "pmc_write")):
+    files = glob.glob(os.path.join(src, d, "*", "*_counter_collection.csv"))
+    if not files:
+        continue
+    per = {}
+    for r in csv.DictReader(open(files[0])):
+        if r["Counter_Name"] != counter:
+            continue
+        k = short(r["Kernel_Name"])
+        per.setdefault(k, []).append((float(r["Counter_Value"]), int(r["End_Timestamp"]) - int(r["Start_Timestamp"])))
+    for k, v in per.items():
+        # skip warm-up-sized outliers: average over all launches of the kernel
+        pmc.setdefault(k, {})[counter + "_KiB_avg"] = sum(x[0] for x in v) / len(v)
+        pmc[k][counter + "_launches"] = len(v)
+        pmc[k]["avg_ns_under_" + counter] = sum(x[1] for x in v) / len(v)
+for k, v in pmc.items():
+    f_, w_ = v.get("FETCH_SIZE_KiB_avg"), v.get("WRITE_SIZE_KiB_avg")
+    if f_ is not None and w_ is not None:
+        v["hbm_read_bytes_per_launch"] = 2 * f_ * 1024      # gfx950 correction for 16 B/lane streams
+        v["hbm_write_bytes_per_launch"] = w_ * 1024
+        v["hbm_bytes_per_launch"] = v["hbm_read_bytes_per_launch"] + v["hbm_write_bytes_per_launch"]
+bench = {}
+for line in open(os.path.join(src, "bench_trace.log")):
+    if line.startswith("{"):
+        bench = json.loads(line)
+out = {"tag": tag, "bench_line_under_kernel_trace": bench, "kernels": pmc}
+json.dump(out, open(os.path.join(ROOT, "profiles", f"{rnd}_{tag}_pmc.json"), "w"), indent=1)
+if "k_scatter_units" in pmc and "hbm_bytes_per_launch" in pmc["k_scatter_units"]:
+    m = re.search(r"^(\d+) x", bench.get("config", {}).get("workload", ""))
+    b = re.search(r"\((\d+)\+(\d+) bit\)", bench.get("config", {}).get("workload", ""))
+    json.dump({"tuples": int(m.group(1)) if m else None, "bits": [int(b.group(1)), int(b.group(2))] if b else None,
+               "scatter_hbm_bytes_per_launch": pmc["k_scatter_units"]["hbm_bytes_per_launch"],
+               "source": f"profiles/{rnd}_{tag}_pmc.json"}, open(os.path.join(ROOT, "profiles", "traffic.json"), "w"), indent=1)
+for r in rows[:8]:
+    print(f'{short(r["Name"]):28s} calls={r["Calls"]:>4s} avg={float(r["AverageNs"])/1e6:9.3f} ms  {r["Percentage"]}%')
+for k, v in pmc.items():
+    if "hbm_bytes_per_launch" in v:
+        print(f'{k:28s} read={v["hbm_read_bytes_per_launch"]/1e9:8.2f} GB write={v["hbm_write_bytes_per_launch"]/1e9:8.2f} GB per launch')

@@ -13,6 +13,8 @@
 // No MFMA anywhere: the path is 64-bit integer hashing and data movement, bounded by HBM.
 #include "rhj_internal.h"
 
+#include <cstdlib>
+
 namespace {
 
 struct __align__(16) Tup { u64 key; u64 payload; };   // reference structs.h:33-36
@@ -214,7 +216,7 @@ k_scan_units(const u64 *__restrict__ seg_start, const u32 *__restrict__ unit_sta
 __global__ void __launch_bounds__(PART_THREADS)
 k_scatter_units(const Tup *__restrict__ in, Tup *__restrict__ out, const u64 *__restrict__ seg_start,
                 const u32 *__restrict__ unit_start, u32 nseg, u64 L, int shift, int bits,
-                const u64 *__restrict__ unit_base)
+                const u64 *__restrict__ unit_base, int ablate)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const u32 nbins = 1u << bits, mask = nbins - 1;
@@ -249,7 +251,7 @@ k_scatter_units(const Tup *__restrict__ in, Tup *__restrict__ out, const u64 *__
 #pragma unroll
         for (int k = 0; k < PART_TPT; k++) {
             const u32 i = k * PART_THREADS + tid;
-            if (i < ntile) rk[k] = atomicAdd(&cnt[(u32)(t[k].payload >> shift) & mask], 1u);
+            if (i < ntile) rk[k] = (ablate & 4) ? 0u : atomicAdd(&cnt[(u32)(t[k].payload >> shift) & mask], 1u);
         }
         __syncthreads();
         {   // exclusive scan of cnt -> excl
@@ -264,7 +266,7 @@ k_scatter_units(const Tup *__restrict__ in, Tup *__restrict__ out, const u64 *__
 #pragma unroll
         for (int k = 0; k < PART_TPT; k++) {
             const u32 i = k * PART_THREADS + tid;
-            if (i < ntile) tile[excl[(u32)(t[k].payload >> shift) & mask] + rk[k]] = t[k];
+            if (i < ntile) tile[(ablate & 4) ? i : excl[(u32)(t[k].payload >> shift) & mask] + rk[k]] = t[k];
         }
         __syncthreads();
 #pragma unroll
@@ -273,12 +275,302 @@ k_scatter_units(const Tup *__restrict__ in, Tup *__restrict__ out, const u64 *__
             if (i < ntile) {
                 const Tup v = tile[i];
                 const u32 dg = (u32)(v.payload >> shift) & mask;
-                out[gbase[dg] + (i - excl[dg])] = v;
+                const u64 dst = gbase[dg] + (i - excl[dg]);
+                if (ablate & 8) {       // timing-only: data-independent, line-aligned runs of TILE/nbins tuples
+                    const u32 per = PART_TILE >> bits;
+                    const u64 fd = (u64)((i / per) & mask) * (L * unit_start[nseg] >> bits) + ((tb >> bits) + (i % per));  // < L*units <= n when n % L == 0
+                    out[fd] = v;
+                } else
+                if (ablate & 1) { if (dst == 0x7fffffffffffffffull) out[0] = v; }
+                else if (ablate & 2) out[tb + i] = v;
+                else out[dst] = v;
             }
         }
         __syncthreads();
         for (u32 b = tid; b < nbins; b += PART_THREADS) { gbase[b] += cnt[b]; cnt[b] = 0; }
         __syncthreads();
+    }
+}
+
+
+// ------------------------------------------------------------------------------------------------
+// K3 (pipelined form).  Same contract as k_scatter_units, restructured for latency:
+//   * the next tile's 16 B/lane loads are issued into a second register set before the current
+//     tile is processed (plain loads survive __syncthreads on gfx950), so HBM latency overlaps
+//     the LDS phases and the stores of the current tile;
+//   * 3 workgroup barriers per tile instead of 7: one wavefront does the nbins-wide exclusive scan
+//     and maintains the unit's global write cursors (gbase) and gdelta[d] = gbase[d] - excl[d],
+//     so a staged tuple at LDS slot i goes to out[gdelta[digit] + i].
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(PART_THREADS, 4)
+k_scatter_units_pipe(const Tup *__restrict__ in, Tup *__restrict__ out, const u64 *__restrict__ seg_start,
+                     const u32 *__restrict__ unit_start, u32 nseg, u64 L, int shift, int bits,
+                     const u64 *__restrict__ unit_base)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const u32 nbins = 1u << bits, mask = nbins - 1;
+    Tup *tile = reinterpret_cast<Tup *>(smem);                               // PART_TILE * 16 B
+    u64 *gbase = reinterpret_cast<u64 *>(smem + (size_t)PART_TILE * 16);     // nbins * 8
+    u64 *gdelta = gbase + nbins;                                             // nbins * 8
+    u32 *cnt = reinterpret_cast<u32 *>(gdelta + nbins);                      // nbins * 4
+    u32 *excl = cnt + nbins;                                                 // nbins * 4
+
+    const u32 u = blockIdx.x;
+    if (u >= unit_start[nseg]) return;
+    const u32 s = find_segment(unit_start, nseg, u);
+    const u64 beg = seg_start[s] + (u64)(u - unit_start[s]) * L;
+    const u64 send = seg_start[s + 1];
+    const u64 end = (beg + L < send) ? beg + L : send;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const u32 bpl = nbins >= 64 ? nbins >> 6 : 1;                            // bins per lane of the scanning wave
+
+    for (u32 b = tid; b < nbins; b += PART_THREADS) { gbase[b] = unit_base[(u64)u * nbins + b]; cnt[b] = 0; }
+    __syncthreads();
+
+    auto load_tile = [&](Tup (&t)[PART_TPT], u64 tb) {
+        const u32 ntile = (end - tb < (u64)PART_TILE) ? (u32)(end - tb) : (u32)PART_TILE;
+        const Tup *__restrict__ tp = in + tb;            // wave-uniform base + 32-bit lane offsets
+#pragma unroll
+        for (int k = 0; k < PART_TPT; k++) {
+            const u32 i = k * PART_THREADS + tid;
+            if (i < ntile) t[k] = tp[i];
+        }
+    };
+    auto process = [&](Tup (&t)[PART_TPT], u64 tb) {
+        const u32 ntile = (end - tb < (u64)PART_TILE) ? (u32)(end - tb) : (u32)PART_TILE;
+        u32 rk[PART_TPT];
+#pragma unroll
+        for (int k = 0; k < PART_TPT; k++) {
+            const u32 i = k * PART_THREADS + tid;
+            if (i < ntile) rk[k] = atomicAdd(&cnt[(u32)(t[k].payload >> shift) & mask], 1u);
+        }
+        __syncthreads();
+        if (wave == 0) {
+            const u32 b0 = lane * bpl;
+            u32 loc = 0;
+            for (u32 j = 0; j < bpl; j++) if (b0 + j < nbins) loc += cnt[b0 + j];
+            u32 ex = wave_incl_scan(loc, lane) - loc;
+            for (u32 j = 0; j < bpl; j++) {
+                const u32 b = b0 + j;
+                if (b < nbins) {
+                    const u32 c = cnt[b];
+                    const u64 g = gbase[b];
+                    excl[b] = ex;
+                    gdelta[b] = g - ex;
+                    gbase[b] = g + c;
+                    cnt[b] = 0;
+                    ex += c;
+                }
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < PART_TPT; k++) {
+            const u32 i = k * PART_THREADS + tid;
+            if (i < ntile) tile[excl[(u32)(t[k].payload >> shift) & mask] + rk[k]] = t[k];
+        }
+        __syncthreads();
+#pragma unroll
+        for (int h = 0; h < PART_TPT; h += 4) {      // two halves: bounds the live registers of this phase
+#pragma unroll
+            for (int k = h; k < h + 4; k++) {
+                const u32 i = k * PART_THREADS + tid;
+                if (i < ntile) {
+                    const Tup v = tile[i];
+                    out[gdelta[(u32)(v.payload >> shift) & mask] + i] = v;
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    };
+
+    Tup ta[PART_TPT], tb_[PART_TPT];
+    u64 cur = beg;
+    if (cur < end) load_tile(ta, cur);
+    while (cur < end) {
+        u64 nxt = cur + PART_TILE;
+        if (nxt < end) load_tile(tb_, nxt);
+        process(ta, cur);
+        cur = nxt;
+        if (cur >= end) break;
+        nxt = cur + PART_TILE;
+        if (nxt < end) load_tile(ta, nxt);
+        process(tb_, cur);
+        cur = nxt;
+    }
+}
+
+
+// ------------------------------------------------------------------------------------------------
+// K3 (line-aligned write-combining form) -- the production scatter kernel.
+//
+// Measured on MI355X (profiles/): the tile-sort scatter above moves the ideal number of
+// bytes but runs at 3.3-3.9 TB/s because every digit run starts and ends at an arbitrary 16 B
+// offset, so about half of the 128 B lines it touches are written in two pieces by two different
+// tiles, microseconds apart, after the first piece has already left the L2.  The same kernel with
+// line-aligned runs sustains 5.2 TB/s at any fan-out.  This form therefore writes ONLY full,
+// 128 B-aligned lines (8 tuples), except for the first and last line of each digit of a unit:
+//   cb[d][8]   carry line of digit d in LDS: the tuples of the not yet complete line, at slot
+//              (global index & 7)
+//   per tile   new tuples of digit d get global indices [g0, e).  With a = first line boundary
+//              >= g0 and b = last line boundary <= e:
+//                 [g0, a)  "head"   -> cb[d] directly (completes the carried line -> flushed as one
+//                                      128 B store by 8 adjacent lanes)
+//                 [a, b)   "middle" -> staged in LDS in digit order, flushed as whole lines
+//                 [b, e)   "tail"   -> staged, then moved to cb[d] after the flush (carried on)
+// One workgroup of 1024 threads per CU (tile 64 KiB + carry lines nbins*128 B), next tile's 16 B/lane
+// loads prefetched into a second register set, 4 workgroup barriers per tile.
+// ------------------------------------------------------------------------------------------------
+constexpr int WC_THREADS = 1024, WC_TPT = 4, WC_TILE = WC_THREADS * WC_TPT;
+constexpr int WC_MAX_BITS = 9;
+
+__global__ void __launch_bounds__(WC_THREADS)
+k_scatter_wc(const Tup *__restrict__ in, Tup *__restrict__ out, const u64 *__restrict__ seg_start,
+             const u32 *__restrict__ unit_start, u32 nseg, u64 L, int shift, int bits,
+             const u64 *__restrict__ unit_base)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const u32 nbins = 1u << bits, mask = nbins - 1;
+    Tup *tile = reinterpret_cast<Tup *>(smem);                               // WC_TILE * 16
+    Tup *cb = tile + WC_TILE;                                                // nbins * 8 * 16
+    u64 *gnext = reinterpret_cast<u64 *>(cb + (size_t)nbins * 8);            // next global index per digit
+    u64 *A = gnext + nbins;                                                  // staging slot i -> global index A[d] + i
+    u64 *LB = A + nbins;                                                     // carry-line flush: (line base | first slot), ~0 = none
+    u32 *cnt = reinterpret_cast<u32 *>(LB + nbins);
+    u32 *P = cnt + nbins;                                                    // sexcl | heads << 16 | (g0 & 7) << 20
+    u32 *LO = P + nbins;                                                     // first valid slot of the carried line
+    u32 *mtot = LO + nbins;                                                  // staged tuples of this tile
+
+    const u32 u = blockIdx.x;
+    if (u >= unit_start[nseg]) return;
+    const u32 s = find_segment(unit_start, nseg, u);
+    const u64 beg = seg_start[s] + (u64)(u - unit_start[s]) * L;
+    const u64 send = seg_start[s + 1];
+    const u64 end = (beg + L < send) ? beg + L : send;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const u32 bpl = nbins >= 64 ? nbins >> 6 : 1;
+
+    for (u32 b = tid; b < nbins; b += WC_THREADS) {
+        const u64 g = unit_base[(u64)u * nbins + b];
+        gnext[b] = g;
+        LO[b] = (u32)g & 7u;
+        cnt[b] = 0;
+    }
+    __syncthreads();
+
+    auto load_tile = [&](Tup (&t)[WC_TPT], u64 tb) {
+        const u32 ntile = (end - tb < (u64)WC_TILE) ? (u32)(end - tb) : (u32)WC_TILE;
+        const Tup *__restrict__ tp = in + tb;
+#pragma unroll
+        for (int k = 0; k < WC_TPT; k++) {
+            const u32 i = k * WC_THREADS + tid;
+            if (i < ntile) t[k] = tp[i];
+        }
+    };
+    auto process = [&](Tup (&t)[WC_TPT], u64 tb) {
+        const u32 ntile = (end - tb < (u64)WC_TILE) ? (u32)(end - tb) : (u32)WC_TILE;
+        u32 rk[WC_TPT];
+#pragma unroll
+        for (int k = 0; k < WC_TPT; k++) {
+            const u32 i = k * WC_THREADS + tid;
+            if (i < ntile) rk[k] = atomicAdd(&cnt[(u32)(t[k].payload >> shift) & mask], 1u);
+        }
+        __syncthreads();                                                     // B1: counts complete
+        if (wave == 0) {
+            const u32 b0 = lane * bpl;
+            u32 loc = 0;
+            for (u32 j = 0; j < bpl; j++) {
+                const u32 b = b0 + j;
+                if (b < nbins) {
+                    const u64 g0 = gnext[b], e = g0 + cnt[b], a = (g0 + 7) & ~7ull;
+                    loc += (e >= a) ? (u32)(e - a) : 0u;
+                }
+            }
+            const u32 inc = wave_incl_scan(loc, lane);
+            u32 sx = inc - loc;
+            for (u32 j = 0; j < bpl; j++) {
+                const u32 b = b0 + j;
+                if (b < nbins) {
+                    const u32 c = cnt[b];
+                    const u64 g0 = gnext[b], e = g0 + c, a = (g0 + 7) & ~7ull;
+                    const bool crossed = e >= a;
+                    const u32 m = crossed ? (u32)(e - a) : 0u;
+                    const u32 heads = crossed ? (u32)(a - g0) : c;             // tuples that go straight to cb
+                    P[b] = sx | (heads << 16) | (((u32)g0 & 7u) << 28);
+                    A[b] = a - sx;
+                    if (crossed && ((u32)g0 & 7u)) { LB[b] = (a - 8) | LO[b]; LO[b] = 0; }
+                    else LB[b] = ~0ull;
+                    gnext[b] = e;
+                    cnt[b] = 0;
+                    sx += m;
+                }
+            }
+            if (lane == 63) *mtot = inc;
+        }
+        __syncthreads();                                                     // S2: plan visible
+#pragma unroll
+        for (int k = 0; k < WC_TPT; k++) {
+            const u32 i = k * WC_THREADS + tid;
+            if (i < ntile) {
+                const u32 d = (u32)(t[k].payload >> shift) & mask;
+                const u32 p = P[d], heads = (p >> 16) & 0xfffu;
+                if (rk[k] < heads) cb[d * 8 + (p >> 28) + rk[k]] = t[k];
+                else tile[(p & 0xffffu) + rk[k] - heads] = t[k];
+            }
+        }
+        __syncthreads();                                                     // D: cb heads + staging complete
+        for (u32 q = tid; q < nbins * 8; q += WC_THREADS) {                  // completed carry lines: 8 lanes = one 128 B line
+            const u32 d = q >> 3, j = q & 7;
+            const u64 x = LB[d];
+            if (x != ~0ull && j >= ((u32)x & 7u)) out[(x & ~7ull) + j] = cb[q];
+        }
+        const u32 mt = *mtot;
+        u32 keep = 0;
+#pragma unroll
+        for (int k = 0; k < WC_TPT; k++) {
+            const u32 i = k * WC_THREADS + tid;
+            if (i < mt) {
+                const Tup v = tile[i];
+                const u32 d = (u32)(v.payload >> shift) & mask;
+                const u64 g = A[d] + i;
+                if (g < (gnext[d] & ~7ull)) out[g] = v;                       // whole lines [a, b)
+                else keep |= 1u << k;                                         // tail [b, e): carried on
+            }
+        }
+        __syncthreads();                                                     // F: carry lines read, tails may overwrite them
+        if (keep) {
+#pragma unroll
+            for (int k = 0; k < WC_TPT; k++) {
+                if (keep & (1u << k)) {
+                    const u32 i = k * WC_THREADS + tid;
+                    const Tup v = tile[i];
+                    const u32 d = (u32)(v.payload >> shift) & mask;
+                    cb[d * 8 + ((u32)(A[d] + i) & 7u)] = v;
+                }
+            }
+        }
+    };
+
+    Tup ta[WC_TPT], tb_[WC_TPT];
+    u64 cur = beg;
+    if (cur < end) load_tile(ta, cur);
+    while (cur < end) {
+        u64 nxt = cur + WC_TILE;
+        if (nxt < end) load_tile(tb_, nxt);
+        process(ta, cur);
+        cur = nxt;
+        if (cur >= end) break;
+        nxt = cur + WC_TILE;
+        if (nxt < end) load_tile(ta, nxt);
+        process(tb_, cur);
+        cur = nxt;
+    }
+    __syncthreads();
+    // unit end: the still incomplete line of every digit (shared with the next unit's first line)
+    for (u32 q = tid; q < nbins * 8; q += WC_THREADS) {
+        const u32 d = q >> 3, j = q & 7;
+        const u64 g = gnext[d];
+        if (j >= LO[d] && j < ((u32)g & 7u)) out[(g & ~7ull) + j] = cb[q];
     }
 }
 
@@ -564,7 +856,13 @@ k_generate(int kind, Tup *__restrict__ out, u64 n, u64 row0, u64 D, u64 seed, do
 size_t part_lds_bytes(int bits)
 {
     const size_t nbins = (size_t)1 << bits;
-    return (size_t)PART_TILE * 16 + nbins * (8 + 4 + 4) + (PART_THREADS / 64) * 4;
+    return (size_t)PART_TILE * 16 + nbins * (8 + 8 + 4 + 4) + (PART_THREADS / 64) * 4;
+}
+
+static size_t wc_lds_bytes(int bits)
+{
+    const size_t nbins = (size_t)1 << bits;
+    return (size_t)WC_TILE * 16 + nbins * (128 + 8 + 8 + 8 + 4 + 4 + 4) + 16;
 }
 
 size_t join_lds_bytes()
@@ -580,6 +878,10 @@ static void allow_big_lds()
     done = true;
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_scatter_units),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)part_lds_bytes(PART_MAX_BITS));
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_scatter_units_pipe),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)part_lds_bytes(PART_MAX_BITS));
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_scatter_wc),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)wc_lds_bytes(WC_MAX_BITS));
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_join),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)join_lds_bytes());
 }
@@ -616,9 +918,22 @@ void launch_scatter_units(hipStream_t st, const void *d_in, void *d_out, const P
 {
     if (g.max_units == 0) return;
     allow_big_lds();
+    static const int variant = getenv("RHJ_SCATTER") ? atoi(getenv("RHJ_SCATTER")) : 2;
+    if (variant == 2 && g.bits <= WC_MAX_BITS) {
+        hipLaunchKernelGGL(k_scatter_wc, dim3(g.max_units), dim3(WC_THREADS), wc_lds_bytes(g.bits), st,
+                           (const Tup *)d_in, (Tup *)d_out, d_seg_start, d_unit_start, g.nseg, g.L, g.shift, g.bits,
+                           d_unit_base);
+        return;
+    }
+    if (variant >= 1) {
+        hipLaunchKernelGGL(k_scatter_units_pipe, dim3(g.max_units), dim3(PART_THREADS), part_lds_bytes(g.bits), st,
+                           (const Tup *)d_in, (Tup *)d_out, d_seg_start, d_unit_start, g.nseg, g.L, g.shift, g.bits,
+                           d_unit_base);
+        return;
+    }
     hipLaunchKernelGGL(k_scatter_units, dim3(g.max_units), dim3(PART_THREADS), part_lds_bytes(g.bits), st,
                        (const Tup *)d_in, (Tup *)d_out, d_seg_start, d_unit_start, g.nseg, g.L, g.shift, g.bits,
-                       d_unit_base);
+                       d_unit_base, getenv("RHJ_ABLATE") ? atoi(getenv("RHJ_ABLATE")) : 0);
 }
 
 void launch_diff_hist(hipStream_t st, const u64 *d_start, u64 nbins, u64 *d_hist)

@@ -153,13 +153,13 @@ int ilog2_ceil(u64 x)
 
 // ---- radix plan (host logic) --------------------------------------------------------------------
 // Reference: one fixed 8-bit pass (Result.cpp:5,91).  Here: the fewest radix bits such that the
-// average build-side partition fills at most 3/4 of one LDS hash table, in <= 2 passes.
+// average build-side partition fills at most 15/16 of one LDS hash table (BJ_CHUNK), in <= 2 passes.
 int resolve_plan(u64 nR, u64 nS, const rhj_opts *in, rhj_opts *out)
 {
     rhj_opts o;
     if (in) o = *in; else rhj_default_opts(&o);
     const u64 nb = nR < nS ? nR : nS;
-    const u64 fit = (u64)JOIN_CHUNK * JOIN_FILL_NUM / JOIN_FILL_DEN;
+    const u64 fit = (u64)BJ_FIT;
     if (o.passes < -1 || o.passes > 2 || o.bits1 < 0 || o.bits2 < 0 || o.bits1 > PART_MAX_BITS ||
         o.bits2 > PART_MAX_BITS || o.probe_split < 0)
         return RHJ_E_INVALID;
@@ -167,9 +167,9 @@ int resolve_plan(u64 nR, u64 nS, const rhj_opts *in, rhj_opts *out)
         if (o.bits1 > 0) o.passes = o.bits2 > 0 ? 2 : 1;
         else {
             int bits = 0;
-            if (nb > (u64)JOIN_CHUNK) bits = ilog2_ceil((nb + fit - 1) / fit);
+            if (nb > (u64)BJ_CHUNK) bits = ilog2_ceil((nb + fit - 1) / fit);
             if (bits == 0) o.passes = 0;
-            else if (bits <= 8) { o.passes = 1; o.bits1 = bits; }
+            else if (bits <= 9) { o.passes = 1; o.bits1 = bits; }
             else {
                 if (bits > 2 * PART_MAX_BITS) bits = 2 * PART_MAX_BITS;
                 o.passes = 2; o.bits1 = (bits + 1) / 2; o.bits2 = bits / 2;

@@ -23,12 +23,23 @@ constexpr int JOIN_CHUNK = 6144;                  // build tuples per LDS hash t
 constexpr int JOIN_HEADS = 8192;                  // chain heads (32 KiB)
 constexpr int JOIN_EPT = 4;                       // probe tuples per thread per tile
 constexpr int JOIN_TILE = JOIN_THREADS * JOIN_EPT;
-constexpr int JOIN_FILL_NUM = 3, JOIN_FILL_DEN = 4;  // plan: average build partition <= 3/4 chunk
+constexpr int JOIN_FILL_NUM = 3, JOIN_FILL_DEN = 4;  // (chained-table kernel) average build partition <= 3/4 chunk
 
-struct JoinTask {           // one workgroup's work: probe range [pbeg, pbeg+plen) of partition `part`
-    u64 pbeg;
+// bucketized-table kernel (production): 512 threads, two workgroups per CU
+constexpr int BJ_THREADS = 512;
+constexpr int BJ_CHUNK = 4224;                    // build tuples per LDS table: 66 KiB keys+rowids
+constexpr int BJ_BUCKET_BITS = 11;                // 2048 hash buckets (offsets: 8 KiB)
+constexpr int BJ_EPT = 8;                         // probe tuples per thread per tile
+constexpr int BJ_TILE = BJ_THREADS * BJ_EPT;      // 4096
+constexpr int BJ_FIT = BJ_CHUNK * 15 / 16;        // plan: average build partition <= 3960 tuples
+
+struct JoinTask {           // one workgroup's work: probe range [pbeg, pbeg+plen) against build range [bbeg, bbeg+blen)
+    u64 pbeg;               // absolute index into the probe-side array
     u32 plen;
-    u32 part;
+    u32 part;               // partition id
+    u64 bbeg;               // absolute index into the build-side array
+    u32 blen;
+    u32 build_is_S;         // 1: build on S, probe with R (|R_k| >= |S_k|, JobScheduler.cpp:187)
 };
 
 struct PassGeom {

@@ -624,12 +624,13 @@ k_make_tasks(const u64 *__restrict__ startR, const u64 *__restrict__ startS, u64
     __shared__ u32 wsum[16];
     __shared__ u32 gbase;
     const u64 k = (u64)blockIdx.x * 1024 + threadIdx.x;
-    u32 nt = 0;
-    u64 pbeg = 0, plen = 0;
+    u32 nt = 0, bis = 0;
+    u64 pbeg = 0, plen = 0, bbeg = 0, blen = 0;
     if (k < nparts) {
         const u64 r0 = startR[k], nr = startR[k + 1] - r0, s0 = startS[k], ns = startS[k + 1] - s0;
         if (nr != 0 && ns != 0) {
-            if (nr >= ns) { pbeg = r0; plen = nr; } else { pbeg = s0; plen = ns; }
+            if (nr >= ns) { pbeg = r0; plen = nr; bbeg = s0; blen = ns; bis = 1; }
+            else          { pbeg = s0; plen = ns; bbeg = r0; blen = nr; bis = 0; }
             nt = (u32)((plen + probe_split - 1) / probe_split);
         }
     }
@@ -645,6 +646,9 @@ k_make_tasks(const u64 *__restrict__ startR, const u64 *__restrict__ startS, u64
         const u64 rem = plen - (u64)j * probe_split;
         t.plen = (u32)(rem < probe_split ? rem : probe_split);
         t.part = (u32)k;
+        t.bbeg = bbeg;
+        t.blen = (u32)blen;              // a build side of >= 2^32 tuples in ONE partition is rejected by the host plan
+        t.build_is_S = bis;
         tasks[slot] = t;
     }
 }
@@ -781,6 +785,173 @@ k_join(const Tup *__restrict__ R, const u64 *__restrict__ startR, const Tup *__r
     }
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// K4 (bucketized LDS table) -- the production bucket-join kernel.
+// JoinJob::run + Result::join_buckets (Result.cpp:43-76) + add_result/addAll.  Differences from the
+// chained-table form above, all forced by latency on a 256-CU part:
+//   * 512 threads and <= 80 KiB LDS: two workgroups per CU overlap each other's global-load and
+//     atomic round trips;
+//   * the table is the build chunk itself re-ordered by hash bucket (LDS counting sort: per-bucket
+//     counts by ds_add_rtn, in-place exclusive scan, place), so there is no head/next storage:
+//     probe = read off[h], off[h+1], compare the keys in between (full 64-bit equality);
+//   * the task descriptor carries everything (no dependent loads of partition boundaries) and the
+//     first probe tile is requested from HBM before the table is built;
+//   * output compaction: per probe slot a wavefront ballot + mbcnt prefix when no lane has more
+//     than one match (foreign-key case), a shuffle scan otherwise; one 64-lane scan over the
+//     (slot, wavefront) totals; one global atomicAdd per 4096-tuple probe tile reserves the pairs.
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ u32 bj_bucket(u64 v, int radix_bits)
+{
+    return (u32)(((v >> radix_bits) * 0x9E3779B97F4A7C15ULL) >> (64 - BJ_BUCKET_BITS));
+}
+
+__global__ void __launch_bounds__(BJ_THREADS, 4)
+k_join_bkt(const Tup *__restrict__ R, const Tup *__restrict__ S, const JoinTask *__restrict__ tasks,
+           const u32 *__restrict__ ntasks, int radix_bits, Pair *__restrict__ out, u64 out_capacity,
+           u64 *__restrict__ out_count)
+{
+    constexpr int NB = 1 << BJ_BUCKET_BITS;
+    constexpr int NW = BJ_THREADS / 64;
+    constexpr int BPT = (BJ_CHUNK + BJ_THREADS - 1) / BJ_THREADS;            // build tuples per thread
+    static_assert(BJ_EPT * NW == 64, "the (slot, wavefront) totals are scanned by one 64-lane wavefront");
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    u64 *keys = reinterpret_cast<u64 *>(smem);                               // BJ_CHUNK * 8
+    u64 *rids = keys + BJ_CHUNK;                                             // BJ_CHUNK * 8
+    u32 *off = reinterpret_cast<u32 *>(rids + BJ_CHUNK);                     // NB + 1 (+ pad to 16 B)
+    u32 *wtot = off + NB + 4;                                                // 64: [slot][wave] match totals
+    u32 *wsum = wtot + 64;                                                   // NW scan scratch
+    u64 *gres = reinterpret_cast<u64 *>(wsum + NW);                          // 1
+
+    const u32 nt = *ntasks;
+    if (blockIdx.x >= nt) return;
+    const JoinTask task = tasks[blockIdx.x];
+    const bool build_is_S = task.build_is_S != 0;
+    const Tup *__restrict__ B = (build_is_S ? S : R) + task.bbeg;
+    const Tup *__restrict__ P = (build_is_S ? R : S) + task.pbeg;
+    const u32 nb = task.blen, np = task.plen;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+
+    // first probe tile: in flight while the table is built
+    Tup p[BJ_EPT];
+#pragma unroll
+    for (int k = 0; k < BJ_EPT; k++) {
+        const u32 i = (u32)k * BJ_THREADS + tid;
+        if (i < np) p[k] = P[i];
+    }
+
+    for (u32 cb = 0; cb < nb; cb += BJ_CHUNK) {
+        const u32 nc = (nb - cb < (u32)BJ_CHUNK) ? nb - cb : (u32)BJ_CHUNK;
+        // ---- build: counting sort of the chunk by hash bucket ---------------------------------
+        for (u32 h = tid; h <= NB; h += BJ_THREADS) off[h] = 0;
+        Tup bt[BPT];
+        u32 br[BPT];
+#pragma unroll
+        for (int k = 0; k < BPT; k++) {
+            const u32 i = (u32)k * BJ_THREADS + tid;
+            if (i < nc) bt[k] = B[cb + i];
+        }
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < BPT; k++) {
+            const u32 i = (u32)k * BJ_THREADS + tid;
+            if (i < nc) br[k] = atomicAdd(&off[bj_bucket(bt[k].payload, radix_bits)], 1u);
+        }
+        __syncthreads();
+        {   // in-place exclusive scan of the NB bucket counts (NB / BJ_THREADS consecutive buckets per thread)
+            constexpr int PER = NB / BJ_THREADS;
+            u32 c[PER], loc = 0;
+#pragma unroll
+            for (int j = 0; j < PER; j++) { c[j] = off[tid * PER + j]; loc += c[j]; }
+            u32 tot;
+            u32 ex = block_excl_scan<BJ_THREADS>(loc, wsum, tot);
+#pragma unroll
+            for (int j = 0; j < PER; j++) { off[tid * PER + j] = ex; ex += c[j]; }
+            if (tid == BJ_THREADS - 1) off[NB] = ex;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < BPT; k++) {
+            const u32 i = (u32)k * BJ_THREADS + tid;
+            if (i < nc) {
+                const u32 pos = off[bj_bucket(bt[k].payload, radix_bits)] + br[k];
+                keys[pos] = bt[k].payload;
+                rids[pos] = bt[k].key;
+            }
+        }
+        __syncthreads();
+
+        // ---- probe ------------------------------------------------------------------------------
+        for (u32 tb = 0; tb < np; tb += BJ_TILE) {
+            if (tb != 0 || cb != 0) {
+#pragma unroll
+                for (int k = 0; k < BJ_EPT; k++) {
+                    const u32 i = tb + (u32)k * BJ_THREADS + tid;
+                    if (i < np) p[k] = P[i];
+                }
+            }
+            u32 cnt[BJ_EPT], pre[BJ_EPT];
+#pragma unroll
+            for (int k = 0; k < BJ_EPT; k++) {
+                const u32 i = tb + (u32)k * BJ_THREADS + tid;
+                cnt[k] = 0;
+                if (i < np) {
+                    const u32 h = bj_bucket(p[k].payload, radix_bits);
+                    const u32 hi = off[h + 1];
+                    for (u32 j = off[h]; j < hi; j++) cnt[k] += (keys[j] == p[k].payload) ? 1u : 0u;
+                }
+            }
+            // per slot: exclusive prefix of the match counts inside the wavefront
+#pragma unroll
+            for (int k = 0; k < BJ_EPT; k++) {
+                u32 tot;
+                if (__ballot(cnt[k] > 1) == 0) {                              // foreign-key case: ballot + mbcnt
+                    const unsigned long long m = __ballot(cnt[k] != 0);
+                    pre[k] = __builtin_amdgcn_mbcnt_hi((u32)(m >> 32), __builtin_amdgcn_mbcnt_lo((u32)m, 0u));
+                    tot = (u32)__popcll(m);
+                } else {
+                    const u32 inc = wave_incl_scan(cnt[k], lane);
+                    pre[k] = inc - cnt[k];
+                    tot = __shfl(inc, 63, 64);
+                }
+                if (lane == 0) wtot[k * NW + w] = tot;
+            }
+            __syncthreads();
+            // every wavefront scans the 64 (slot, wave) totals itself: no second barrier
+            const u32 mine = wtot[lane];
+            const u32 inc64 = wave_incl_scan(mine, lane);
+            const u32 tile_total = __shfl(inc64, 63, 64);
+            if (tid == 0 && tile_total) *gres = atomicAdd(out_count, (u64)tile_total);
+            __syncthreads();
+            if (tile_total && out != nullptr) {
+                const u64 g = *gres;
+#pragma unroll
+                for (int k = 0; k < BJ_EPT; k++) {
+                    const u32 sbase = __shfl(inc64 - mine, k * NW + w, 64);   // exclusive prefix of (slot k, wave w)
+                    if (cnt[k]) {
+                        u64 o = g + sbase + pre[k];
+                        const u32 h = bj_bucket(p[k].payload, radix_bits);
+                        const u32 hi = off[h + 1];
+                        for (u32 j = off[h]; j < hi; j++) {
+                            if (keys[j] == p[k].payload) {
+                                if (o < out_capacity) {
+                                    Pair pr;
+                                    if (build_is_S) { pr.r = p[k].key; pr.s = rids[j]; }   // orderFlag, Result.cpp:64-68
+                                    else            { pr.r = rids[j]; pr.s = p[k].key; }
+                                    out[o] = pr;
+                                }
+                                o++;
+                            }
+                        }
+                    }
+                }
+            }
+            // wtot / gres are rewritten only after the next tile's first barrier: safe without another one
+        }
+        __syncthreads();         // the table is rebuilt by the next chunk
+    }
+}
+
 // ------------------------------------------------------------------------------------------------
 // utilities
 // ------------------------------------------------------------------------------------------------
@@ -865,6 +1036,11 @@ static size_t wc_lds_bytes(int bits)
     return (size_t)WC_TILE * 16 + nbins * (128 + 8 + 8 + 8 + 4 + 4 + 4) + 16;
 }
 
+static size_t bj_lds_bytes()
+{
+    return (size_t)BJ_CHUNK * 16 + ((size_t)(1 << BJ_BUCKET_BITS) + 4) * 4 + 64 * 4 + (BJ_THREADS / 64) * 4 + 16;
+}
+
 size_t join_lds_bytes()
 {
     return (size_t)JOIN_CHUNK * 16 + (size_t)JOIN_HEADS * 4 + (size_t)JOIN_CHUNK * 2 +
@@ -882,6 +1058,8 @@ static void allow_big_lds()
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)part_lds_bytes(PART_MAX_BITS));
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_scatter_wc),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)wc_lds_bytes(WC_MAX_BITS));
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_join_bkt),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)bj_lds_bytes());
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_join),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)join_lds_bytes());
 }
@@ -959,6 +1137,12 @@ void launch_join(hipStream_t st, const void *d_R, const u64 *d_startR, const voi
 {
     if (grid == 0) return;
     allow_big_lds();
+    static const int variant = getenv("RHJ_JOIN") ? atoi(getenv("RHJ_JOIN")) : 1;
+    if (variant == 1) {
+        hipLaunchKernelGGL(k_join_bkt, dim3(grid), dim3(BJ_THREADS), bj_lds_bytes(), st, (const Tup *)d_R,
+                           (const Tup *)d_S, d_tasks, d_ntasks, radix_bits, (Pair *)d_out, out_capacity, d_out_count);
+        return;
+    }
     hipLaunchKernelGGL(k_join, dim3(grid), dim3(JOIN_THREADS), join_lds_bytes(), st, (const Tup *)d_R, d_startR,
                        (const Tup *)d_S, d_startS, d_tasks, d_ntasks, radix_bits, (Pair *)d_out, out_capacity,
                        d_out_count);

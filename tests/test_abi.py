@@ -38,12 +38,12 @@ def test_layouts_match_reference_structs():
 def test_plan_auto():
     P, O = binding.plan, rhj.Opts
     assert P(1, 1561).passes == 0                       # tiny build side: no partitioning (one LDS table)
-    assert P(6144, 10**6).passes == 0
-    assert P(6145, 10**6).passes == 1
+    assert P(4224, 10**6).passes == 0                   # BJ_CHUNK tuples fit one LDS table
+    assert P(4225, 10**6).passes == 1
     p = P(10**6, 10**6)
     assert (p.passes, p.bits1, p.bits2) == (1, 8, 0)    # BASELINE config 2: 1M x 1M, 8-bit, single pass
     p = P(10**9, 10**9)
-    assert p.passes == 2 and p.bits1 + p.bits2 == 18    # avg build partition 3815 <= 3/4 * 6144
+    assert p.passes == 2 and p.bits1 + p.bits2 == 18    # avg build partition 3815 <= 15/16 * 4224
     p = P(10**9, 10**9, O(2, 8, 8))
     assert (p.passes, p.bits1, p.bits2) == (2, 8, 8)    # BASELINE config 3 as named
     assert P(10**9, 5).passes == 0

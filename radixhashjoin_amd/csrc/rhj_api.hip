@@ -43,7 +43,7 @@ struct rhj_ctx {
     DevBuf seg0, unit_start, unit_hist, unit_base;
     DevBuf tasks, counters;            // counters: [0] u64 out_count, [1] u32 ntasks (+pad), [2] u64 checksum
     DevBuf out_pairs;                  // rhj_join's device result buffer
-    DevBuf hist_tmp;
+    DevBuf hist_tmp, scan_tmp;
     // state of the last partition phase (consumed by join_phase)
     const void *cur_R = nullptr, *cur_S = nullptr;
     const u64 *cur_psR = nullptr, *cur_psS = nullptr;
@@ -216,6 +216,7 @@ int run_pass(rhj_ctx *ctx, const void *d_in, void *d_out, u64 n, const u64 *d_se
     RHJCHK(ensure(ctx, ctx->unit_start, ((size_t)nseg + 1) * 4));
     RHJCHK(ensure(ctx, ctx->unit_hist, (size_t)g.max_units * nbins * 4));
     RHJCHK(ensure(ctx, ctx->unit_base, (size_t)g.max_units * nbins * 8));
+    RHJCHK(ensure(ctx, ctx->scan_tmp, scan_tmp_bytes(bits)));
     u32 *unit_start = (u32 *)ctx->unit_start.p;
     {
         Span s(ctx, RHJ_K_AUX);
@@ -228,7 +229,7 @@ int run_pass(rhj_ctx *ctx, const void *d_in, void *d_out, u64 n, const u64 *d_se
     {
         Span s(ctx, RHJ_K_SCAN);
         launch_scan_units(ctx->stream, g, d_seg_start, unit_start, (const u32 *)ctx->unit_hist.p,
-                          (u64 *)ctx->unit_base.p, d_part_start);
+                          (u64 *)ctx->unit_base.p, d_part_start, (u64 *)ctx->scan_tmp.p);
     }
     {
         Span s(ctx, RHJ_K_SCATTER);
@@ -396,7 +397,7 @@ int rhj_release_workspace(rhj_ctx *ctx)
     (void)hipStreamSynchronize(ctx->stream);
     DevBuf *all[] = {&ctx->in_R, &ctx->in_S, &ctx->part_R, &ctx->part_S, &ctx->part_tmp, &ctx->ps_R, &ctx->ps_S,
                      &ctx->ps_1, &ctx->seg0, &ctx->unit_start, &ctx->unit_hist, &ctx->unit_base, &ctx->tasks,
-                     &ctx->counters, &ctx->out_pairs, &ctx->hist_tmp};
+                     &ctx->counters, &ctx->out_pairs, &ctx->hist_tmp, &ctx->scan_tmp};
     for (DevBuf *b : all) release(*b);
     return RHJ_OK;
 }
@@ -553,6 +554,7 @@ int rhj_histogram(rhj_ctx *ctx, const rhj_tuple *d_rel, uint64_t n, int shift, i
     RHJCHK(ensure(ctx, ctx->unit_start, 8));
     RHJCHK(ensure(ctx, ctx->unit_hist, (size_t)g.max_units * nbins * 4));
     RHJCHK(ensure(ctx, ctx->unit_base, (size_t)g.max_units * nbins * 8));
+    RHJCHK(ensure(ctx, ctx->scan_tmp, scan_tmp_bytes(bits)));
     {
         Span s(ctx, RHJ_K_AUX);
         launch_init_single_segment(ctx->stream, n, g.L, seg0, (u32 *)ctx->unit_start.p);
@@ -564,7 +566,7 @@ int rhj_histogram(rhj_ctx *ctx, const rhj_tuple *d_rel, uint64_t n, int shift, i
     {
         Span s(ctx, RHJ_K_SCAN);
         launch_scan_units(ctx->stream, g, seg0, (const u32 *)ctx->unit_start.p, (const u32 *)ctx->unit_hist.p,
-                          (u64 *)ctx->unit_base.p, (u64 *)ctx->hist_tmp.p);
+                          (u64 *)ctx->unit_base.p, (u64 *)ctx->hist_tmp.p, (u64 *)ctx->scan_tmp.p);
         launch_diff_hist(ctx->stream, (const u64 *)ctx->hist_tmp.p, nbins, (u64 *)d_hist);
     }
     return check_launch(ctx, "rhj_histogram");

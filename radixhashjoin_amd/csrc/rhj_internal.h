@@ -57,7 +57,7 @@ void launch_make_units(hipStream_t st, const u64 *d_seg_start, u32 nseg, u64 L, 
 void launch_hist_units(hipStream_t st, const void *d_in, const PassGeom &g, const u64 *d_seg_start,
                        const u32 *d_unit_start, u32 *d_unit_hist);
 void launch_scan_units(hipStream_t st, const PassGeom &g, const u64 *d_seg_start, const u32 *d_unit_start,
-                       const u32 *d_unit_hist, u64 *d_unit_base, u64 *d_part_start);
+                       const u32 *d_unit_hist, u64 *d_unit_base, u64 *d_part_start, u64 *d_scan_tmp);
 void launch_scatter_units(hipStream_t st, const void *d_in, void *d_out, const PassGeom &g,
                           const u64 *d_seg_start, const u32 *d_unit_start, const u64 *d_unit_base);
 void launch_diff_hist(hipStream_t st, const u64 *d_start, u64 nbins, u64 *d_hist);
@@ -71,4 +71,5 @@ void launch_checksum(hipStream_t st, const void *d_pairs, u64 n, u64 *d_sum);
 void launch_generate(hipStream_t st, int kind, void *d_out, u64 n, u64 row0, u64 D, u64 seed, double theta);
 void launch_expected_pkfk(hipStream_t st, const void *d_S, u64 n, u64 *d_sum);
 size_t join_lds_bytes();
+size_t scan_tmp_bytes(int bits);
 size_t part_lds_bytes(int bits);

@@ -205,6 +205,80 @@ k_scan_units(const u64 *__restrict__ seg_start, const u32 *__restrict__ unit_sta
     }
 }
 
+
+// K2 for ONE long segment (pass 1: up to ~2048 units): the same result as k_scan_units, computed by
+// SCAN_SLICES workgroups in three short launches instead of one workgroup walking every unit.
+constexpr u32 SCAN_SLICES = 64;
+
+__device__ __forceinline__ void slice_range(u32 nu, u32 k, u32 &ub, u32 &ue)
+{
+    const u32 per = (nu + SCAN_SLICES - 1) / SCAN_SLICES;
+    ub = k * per < nu ? k * per : nu;
+    ue = (k + 1) * per < nu ? (k + 1) * per : nu;
+}
+
+// partial[k][d] = sum of hist[u][d] over the units of slice k
+__global__ void __launch_bounds__(1024)
+k_scan1_partial(const u32 *__restrict__ unit_start, int bits, const u32 *__restrict__ unit_hist, u64 *__restrict__ partial)
+{
+    const u32 nbins = 1u << bits, nu = unit_start[1];
+    u32 ub, ue;
+    slice_range(nu, blockIdx.x, ub, ue);
+    for (u32 d = threadIdx.x; d < nbins; d += 1024) {
+        u64 sum = 0;
+        for (u32 u = ub; u < ue; u++) sum += unit_hist[(u64)u * nbins + d];
+        partial[(u64)blockIdx.x * nbins + d] = sum;
+    }
+}
+
+// partial[k][d] <- part_start[d] + sum_{k'<k} partial[k'][d];  part_start[d] = exclusive prefix of the digit totals
+__global__ void __launch_bounds__(1024)
+k_scan1_mid(int bits, u64 *__restrict__ partial, u64 *__restrict__ part_start, u64 n_total)
+{
+    __shared__ u64 wtot[16];
+    const u32 nbins = 1u << bits;                         // <= 1024
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const u32 d = threadIdx.x;
+    u64 tot = 0;
+    if (d < nbins) for (u32 k = 0; k < SCAN_SLICES; k++) tot += partial[(u64)k * nbins + d];
+    u64 inc = tot;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const u64 t = __shfl_up(inc, off, 64);
+        if (lane >= off) inc += t;
+    }
+    if (lane == 63) wtot[w] = inc;
+    __syncthreads();
+    u64 pre = 0;
+    for (int i = 0; i < w; i++) pre += wtot[i];
+    if (d < nbins) {
+        u64 run = pre + inc - tot;
+        part_start[d] = run;
+        if (d == nbins - 1) part_start[nbins] = n_total;
+        for (u32 k = 0; k < SCAN_SLICES; k++) {
+            const u64 c = partial[(u64)k * nbins + d];
+            partial[(u64)k * nbins + d] = run;
+            run += c;
+        }
+    }
+}
+
+__global__ void __launch_bounds__(1024)
+k_scan1_final(const u32 *__restrict__ unit_start, int bits, const u32 *__restrict__ unit_hist,
+              const u64 *__restrict__ partial, u64 *__restrict__ unit_base)
+{
+    const u32 nbins = 1u << bits, nu = unit_start[1];
+    u32 ub, ue;
+    slice_range(nu, blockIdx.x, ub, ue);
+    for (u32 d = threadIdx.x; d < nbins; d += 1024) {
+        u64 run = partial[(u64)blockIdx.x * nbins + d];
+        for (u32 u = ub; u < ue; u++) {
+            unit_base[(u64)u * nbins + d] = run;
+            run += unit_hist[(u64)u * nbins + d];
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------------------------
 // K3: scatter-partition one unit, tile by tile.  PartitionJob::run's scatter (JobScheduler.cpp:170-174)
 // fused with the serial merge-gather of structs.cpp:183-194: tuples go straight to their final
@@ -440,6 +514,7 @@ k_scatter_wc(const Tup *__restrict__ in, Tup *__restrict__ out, const u64 *__res
     u32 *P = cnt + nbins;                                                    // sexcl | heads << 16 | (g0 & 7) << 20
     u32 *LO = P + nbins;                                                     // first valid slot of the carried line
     u32 *mtot = LO + nbins;                                                  // staged tuples of this tile
+    u32 *wsc = mtot + 4;                                                     // WC_THREADS/64 wave totals
 
     const u32 u = blockIdx.x;
     if (u >= unit_start[nseg]) return;
@@ -448,7 +523,6 @@ k_scatter_wc(const Tup *__restrict__ in, Tup *__restrict__ out, const u64 *__res
     const u64 send = seg_start[s + 1];
     const u64 end = (beg + L < send) ? beg + L : send;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const u32 bpl = nbins >= 64 ? nbins >> 6 : 1;
 
     for (u32 b = tid; b < nbins; b += WC_THREADS) {
         const u64 g = unit_base[(u64)u * nbins + b];
@@ -476,36 +550,32 @@ k_scatter_wc(const Tup *__restrict__ in, Tup *__restrict__ out, const u64 *__res
             if (i < ntile) rk[k] = atomicAdd(&cnt[(u32)(t[k].payload >> shift) & mask], 1u);
         }
         __syncthreads();                                                     // B1: counts complete
-        if (wave == 0) {
-            const u32 b0 = lane * bpl;
-            u32 loc = 0;
-            for (u32 j = 0; j < bpl; j++) {
-                const u32 b = b0 + j;
-                if (b < nbins) {
-                    const u64 g0 = gnext[b], e = g0 + cnt[b], a = (g0 + 7) & ~7ull;
-                    loc += (e >= a) ? (u32)(e - a) : 0u;
-                }
+        {   // plan of this tile, one digit per thread (nbins <= 512 <= WC_THREADS): staged count m per digit,
+            // workgroup exclusive scan of m, then the per-digit routing words
+            const u32 b = tid;
+            u32 c = 0, m = 0;
+            u64 g0 = 0, e = 0, a = 0;
+            if (b < nbins) {
+                c = cnt[b];
+                g0 = gnext[b]; e = g0 + c; a = (g0 + 7) & ~7ull;
+                m = (e >= a) ? (u32)(e - a) : 0u;
             }
-            const u32 inc = wave_incl_scan(loc, lane);
-            u32 sx = inc - loc;
-            for (u32 j = 0; j < bpl; j++) {
-                const u32 b = b0 + j;
-                if (b < nbins) {
-                    const u32 c = cnt[b];
-                    const u64 g0 = gnext[b], e = g0 + c, a = (g0 + 7) & ~7ull;
-                    const bool crossed = e >= a;
-                    const u32 m = crossed ? (u32)(e - a) : 0u;
-                    const u32 heads = crossed ? (u32)(a - g0) : c;             // tuples that go straight to cb
-                    P[b] = sx | (heads << 16) | (((u32)g0 & 7u) << 28);
-                    A[b] = a - sx;
-                    if (crossed && ((u32)g0 & 7u)) { LB[b] = (a - 8) | LO[b]; LO[b] = 0; }
-                    else LB[b] = ~0ull;
-                    gnext[b] = e;
-                    cnt[b] = 0;
-                    sx += m;
-                }
+            const u32 inc = wave_incl_scan(m, lane);
+            if (lane == 63) wsc[wave] = inc;
+            __syncthreads();                                                 // Sx: wave totals visible
+            if (b < nbins) {
+                u32 sx = inc - m;
+                for (int i = 0; i < wave; i++) sx += wsc[i];
+                const bool crossed = e >= a;
+                const u32 heads = crossed ? (u32)(a - g0) : c;               // tuples that go straight to cb
+                P[b] = sx | (heads << 16) | (((u32)g0 & 7u) << 28);
+                A[b] = a - sx;
+                if (crossed && ((u32)g0 & 7u)) { LB[b] = (a - 8) | LO[b]; LO[b] = 0; }
+                else LB[b] = ~0ull;
+                gnext[b] = e;
+                cnt[b] = 0;
+                if (b == nbins - 1) *mtot = sx + m;
             }
-            if (lane == 63) *mtot = inc;
         }
         __syncthreads();                                                     // S2: plan visible
 #pragma unroll
@@ -1024,6 +1094,8 @@ k_generate(int kind, Tup *__restrict__ out, u64 n, u64 row0, u64 D, u64 seed, do
 // ------------------------------------------------------------------------------------------------
 // launchers
 // ------------------------------------------------------------------------------------------------
+size_t scan_tmp_bytes(int bits) { return (size_t)SCAN_SLICES * ((size_t)8 << bits); }
+
 size_t part_lds_bytes(int bits)
 {
     const size_t nbins = (size_t)1 << bits;
@@ -1033,7 +1105,7 @@ size_t part_lds_bytes(int bits)
 static size_t wc_lds_bytes(int bits)
 {
     const size_t nbins = (size_t)1 << bits;
-    return (size_t)WC_TILE * 16 + nbins * (128 + 8 + 8 + 8 + 4 + 4 + 4) + 16;
+    return (size_t)WC_TILE * 16 + nbins * (128 + 8 + 8 + 8 + 4 + 4 + 4) + 16 + (WC_THREADS / 64) * 4;
 }
 
 static size_t bj_lds_bytes()
@@ -1083,9 +1155,16 @@ void launch_hist_units(hipStream_t st, const void *d_in, const PassGeom &g, cons
 }
 
 void launch_scan_units(hipStream_t st, const PassGeom &g, const u64 *d_seg_start, const u32 *d_unit_start,
-                       const u32 *d_unit_hist, u64 *d_unit_base, u64 *d_part_start)
+                       const u32 *d_unit_hist, u64 *d_unit_base, u64 *d_part_start, u64 *d_scan_tmp)
 {
     const size_t nbins = (size_t)1 << g.bits;
+    if (g.nseg == 1 && g.max_units > 2 * SCAN_SLICES && d_scan_tmp != nullptr) {
+        hipLaunchKernelGGL(k_scan1_partial, dim3(SCAN_SLICES), dim3(1024), 0, st, d_unit_start, g.bits, d_unit_hist, d_scan_tmp);
+        hipLaunchKernelGGL(k_scan1_mid, dim3(1), dim3(1024), 0, st, g.bits, d_scan_tmp, d_part_start, g.n);
+        hipLaunchKernelGGL(k_scan1_final, dim3(SCAN_SLICES), dim3(1024), 0, st, d_unit_start, g.bits, d_unit_hist,
+                           d_scan_tmp, d_unit_base);
+        return;
+    }
     const size_t G = 1024 / nbins;
     hipLaunchKernelGGL(k_scan_units, dim3(g.nseg), dim3(1024), G * nbins * 4, st, d_seg_start, d_unit_start,
                        g.nseg, g.bits, d_unit_hist, d_unit_base, d_part_start, g.n);

@@ -65,6 +65,7 @@ def main():
     ap.add_argument("--dist", choices=["uniform", "zipf"], default="uniform")
     ap.add_argument("--cpu-sample", type=int, default=32_000_000, help="rows per side of the CPU baseline sample (0 = skip)")
     ap.add_argument("--no-verify", action="store_true")
+    ap.add_argument("--no-auto", action="store_true", help="skip the extra (untimed-for-value) run under the automatic radix plan")
     args = ap.parse_args()
 
     import torch
@@ -76,13 +77,22 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
+    if os.environ.get("RHJ_BENCH_BACKEND", "nccl") != "nccl":
+        local_rank = 0                              # rehearsal: every rank on the one visible GPU
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=dev)
+        # RHJ_BENCH_BACKEND=gloo rehearses the multi-rank path with several ranks on ONE GPU (payloads staged
+        # through the host); the real runs use RCCL
+        backend = os.environ.get("RHJ_BENCH_BACKEND", "nccl")
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
 
+    rdev = dev if (dist is None or dist.get_backend() == "nccl") else torch.device("cpu")
     eng = rhj.Engine(local_rank)
     eng.set_stream(torch.cuda.current_stream().cuda_stream)
     n = args.tuples
@@ -101,8 +111,8 @@ def main():
         out = torch.empty((n + 1024, 2), dtype=torch.int64, device=dev)
         eng.reserve(n, n, opts)
 
-        def step():
-            return eng.join_dev(R, n, S, n, out, out.shape[0], opts=opts), out
+        def step(o=opts):
+            return eng.join_dev(R, n, S, n, out, out.shape[0], opts=o), out
     else:
         from radixhashjoin_amd.sharded import ShardedJoin
         sj = ShardedJoin(eng, dist.group.WORLD, local_opts=opts)
@@ -138,15 +148,33 @@ def main():
         chk = eng.pairs_checksum(res, cnt)
         if dist is not None:
             v = torch.tensor([cnt, exp_cnt, chk - (1 << 64) if chk >= (1 << 63) else chk,
-                              exp_chk - (1 << 64) if exp_chk >= (1 << 63) else exp_chk], dtype=torch.int64, device=dev)
+                              exp_chk - (1 << 64) if exp_chk >= (1 << 63) else exp_chk], dtype=torch.int64, device=rdev)
             dist.all_reduce(v)                          # wrapping int64 sums == sums mod 2^64
             ok = bool(v[0] == v[1]) and bool(v[2] == v[3])
         else:
             ok = (cnt == exp_cnt) and (chk == exp_chk)
-    tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+    tmax = torch.tensor([dt], dtype=torch.float64, device=rdev)
     if dist is not None:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     dt = float(tmax.item())
+
+    # N == 1 only, outside the timed region: the same workload under the engine's automatic radix plan
+    auto = None
+    if world == 1 and not args.no_auto:
+        from radixhashjoin_amd.binding import plan as rhj_plan
+        ap_ = rhj_plan(n, n)
+        if (ap_.passes, ap_.bits1, ap_.bits2) != (2, args.bits1, args.bits2):
+            step(ap_)
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for _ in range(args.steps):
+                c2, r2 = step(ap_)
+            torch.cuda.synchronize()
+            d2 = time.perf_counter() - t1
+            ok2 = args.no_verify or (c2 == exp_cnt and eng.pairs_checksum(r2, c2) == exp_chk)
+            auto = {"plan": f"{ap_.passes}-pass ({ap_.bits1}+{ap_.bits2} bit)", "value": 2.0 * n * args.steps / d2,
+                    "unit": "tuples/s", "ms_per_step": d2 / args.steps * 1e3, "verified": bool(ok2)}
+            ok = ok and bool(ok2)
 
     if rank == 0:
         ms_step = dt / args.steps * 1e3
@@ -178,6 +206,8 @@ def main():
                          "partition_pass_GBps": (40.0 * npass_tuples / (part_ms * 1e-3) / 1e9) if part_ms else 0.0},
             "kernel_ms_per_step": {k: v[0] / args.steps for k, v in kt.items()},
         }
+        if auto is not None:
+            line["auto_plan"] = auto
         if world == 1 and args.cpu_sample > 0:
             line["cpu_baseline"] = cpu_baseline(args.cpu_sample)
             line["gpu_over_cpu"] = value / line["cpu_baseline"]["value"]

@@ -51,8 +51,8 @@ typedef enum {
  * that the average build partition fits one LDS table, split over at most two passes. */
 typedef struct {
     int32_t passes;        /* -1 auto, 0, 1 or 2 */
-    int32_t bits1;         /* radix bits of pass 1 (LSBs [0,bits1)), 1..11; 0 = auto */
-    int32_t bits2;         /* radix bits of pass 2 (bits [bits1,bits1+bits2)), 1..11; 0 = auto */
+    int32_t bits1;         /* radix bits of pass 1 (LSBs [0,bits1)), 1..10; 0 = auto */
+    int32_t bits2;         /* radix bits of pass 2 (bits [bits1,bits1+bits2)), 1..10; 0 = auto */
     int32_t probe_split;   /* max probe tuples per join task (skew/load balance); 0 = auto */
 } rhj_opts;
 
@@ -124,6 +124,11 @@ int rhj_prefix(rhj_ctx *ctx, const uint64_t *d_hist, uint64_t nbins, uint64_t *d
  *   the partition boundaries in that order.  Order of tuples INSIDE a partition is unspecified. */
 int rhj_partition(rhj_ctx *ctx, const rhj_tuple *d_in, uint64_t n, int bits1, int bits2,
                   rhj_tuple *d_out, uint64_t *d_part_start);
+/* rhj_partition_at: ONE scatter-partition pass on payload bits [shift, shift+bits): d_out grouped by that
+ *   digit, d_part_start[2^bits + 1].  Used by the multi-GPU driver to split a shard by owner bits before
+ *   the RCCL all-to-all; the owner bits lie above every bit the local plan uses. */
+int rhj_partition_at(rhj_ctx *ctx, const rhj_tuple *d_in, uint64_t n, int shift, int bits,
+                     rhj_tuple *d_out, uint64_t *d_part_start);
 /* rhj_bucket_join: the JoinJob loop of Result.cpp:98-107 + JoinJob::run + Result::join_buckets +
  *   add_result: for every partition k with both sides non-empty, build an LDS hash table on the smaller
  *   side (S when |R_k| >= |S_k|, JobScheduler.cpp:187) and probe with the other; emit (rowR,rowS).

@@ -67,6 +67,7 @@ SYMBOLS = {
     "rhj_histogram": (C.c_int, [_vp, _vp, _u64, C.c_int, C.c_int, _vp]),
     "rhj_prefix": (C.c_int, [_vp, _vp, _u64, _vp]),
     "rhj_partition": (C.c_int, [_vp, _vp, _u64, C.c_int, C.c_int, _vp, _vp]),
+    "rhj_partition_at": (C.c_int, [_vp, _vp, _u64, C.c_int, C.c_int, _vp, _vp]),
     "rhj_bucket_join": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _u64, C.c_int, C.c_int, _vp, _u64, _P(_u64)]),
     "rhj_pairs_checksum_dev": (C.c_int, [_vp, _vp, _u64, _P(_u64)]),
     "rhj_generate_dev": (C.c_int, [_vp, C.c_int, _vp, _u64, _u64, _u64, _u64, C.c_int]),
@@ -249,6 +250,9 @@ class Engine:
 
     def partition(self, d_in, n, bits1, bits2, d_out, d_part_start):
         self._chk(self.lib.rhj_partition(self.ctx, _addr(d_in), n, bits1, bits2, _addr(d_out), _addr(d_part_start)))
+
+    def partition_at(self, d_in, n, shift, bits, d_out, d_part_start):
+        self._chk(self.lib.rhj_partition_at(self.ctx, _addr(d_in), n, shift, bits, _addr(d_out), _addr(d_part_start)))
 
     def bucket_join(self, d_Rp, d_startR, d_Sp, d_startS, nparts, radix_bits, d_out=None, capacity=0,
                     probe_split=0, allow_overflow=False):

@@ -540,6 +540,22 @@ int rhj_partition(rhj_ctx *ctx, const rhj_tuple *d_in, uint64_t n, int bits1, in
     return partition_relation(ctx, d_in, n, bits2 ? 2 : 1, bits1, bits2, d_out, (u64 *)d_part_start);
 }
 
+int rhj_partition_at(rhj_ctx *ctx, const rhj_tuple *d_in, uint64_t n, int shift, int bits, rhj_tuple *d_out,
+                     uint64_t *d_part_start)
+{
+    RHJCHK(use_device(ctx));
+    if (bits < 1 || bits > PART_MAX_BITS || shift < 0 || shift + bits > 64 || !d_out || !d_part_start || (n && !d_in))
+        return fail(ctx, RHJ_E_INVALID, "bad rhj_partition_at argument");
+    prof_reset(ctx);
+    RHJCHK(ensure(ctx, ctx->seg0, 64));
+    u64 *seg0 = (u64 *)ctx->seg0.p;
+    {
+        Span s(ctx, RHJ_K_AUX);
+        launch_init_single_segment(ctx->stream, n, PART_TILE, seg0, (u32 *)(seg0 + 4));
+    }
+    return run_pass(ctx, d_in, d_out, n, seg0, 1, shift, bits, (u64 *)d_part_start);
+}
+
 int rhj_histogram(rhj_ctx *ctx, const rhj_tuple *d_rel, uint64_t n, int shift, int bits, uint64_t *d_hist)
 {
     RHJCHK(use_device(ctx));

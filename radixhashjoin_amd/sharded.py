@@ -1,0 +1,84 @@
+"""Multi-GPU radix hash join: one process per GPU, torch.distributed (backend "nccl" = RCCL over xGMI).
+
+The reference has no distributed path (single process, pthreads).  Sharding:
+both relations are range-sharded by row over the ranks (rowIDs stay global).  The join needs exactly
+ONE exchange step, an all-to-all of tuples by OWNER RADIX BITS:
+
+    owner(tuple) = (payload >> owner_shift) & (world - 1)        (world is a power of two)
+
+  1. every rank splits its shard of R (then S) by owner bits with one scatter-partition pass
+     (rhj_partition_at): tuples for rank d become contiguous, d = 0..world-1;
+  2. a tiny all-to-all of the per-destination counts, then ONE all_to_all_single of the tuples
+     (RCCL: world-1 direct peer sends over xGMI, all links busy at once, no multi-hop);
+  3. every rank now holds ALL tuples of its owner class of both relations and runs the normal
+     single-GPU join (rhj_join_dev: 1-2 radix passes on the low bits + LDS bucket join) locally.
+     Owner bits lie above every bit the local plan can use (2 * 10), so the local plan is untouched.
+Results stay sharded: rank d holds the pairs whose join value belongs to owner class d; the global
+result is the disjoint union (counts add up, no reduction).
+
+All compute runs in the C-ABI engine passed in (HIP kernels); torch supplies device memory and the
+collective.  The engine is duck-typed (partition_at, join_dev) so the exchange logic can be tested
+on CPU ranks with the gloo backend (tests/test_sharded_gloo.py).
+"""
+import torch
+import torch.distributed as dist
+
+OWNER_SHIFT_DEFAULT = 20      # above the 2 x 10 bits a local two-pass plan can use (PART_MAX_BITS = 10)
+
+
+class ShardedJoin:
+    def __init__(self, engine, group=None, local_opts=None, owner_shift=OWNER_SHIFT_DEFAULT):
+        self.engine = engine
+        self.group = group if group is not None else dist.group.WORLD
+        self.world = dist.get_world_size(self.group)
+        self.rank = dist.get_rank(self.group)
+        if self.world & (self.world - 1):
+            raise ValueError("world size must be a power of two (owner = radix bits)")
+        self.owner_bits = self.world.bit_length() - 1
+        self.owner_shift = owner_shift
+        self.local_opts = local_opts
+        self.stats = {}
+
+    # -- step 1+2 for one relation: owner split, count exchange, tuple exchange -------------------
+    def exchange(self, rel, n):
+        """rel: [n,2] int64 tensor of {rowID, join value} on this rank's device.
+        Returns (received [m,2] tensor, m): every tuple of the global relation owned by this rank."""
+        dev = rel.device
+        if self.world == 1:
+            return rel, n
+        staged = torch.empty((max(n, 1), 2), dtype=torch.int64, device=dev)
+        bounds = torch.empty(self.world + 1, dtype=torch.int64, device=dev)
+        self.engine.partition_at(rel, n, self.owner_shift, self.owner_bits, staged, bounds)
+        send_counts = (bounds[1:] - bounds[:-1]).contiguous()
+        recv_counts = torch.empty_like(send_counts)
+        self._a2a(recv_counts, send_counts, None, None)
+        in_splits = send_counts.tolist()          # host sync: the exchange sizes must be known
+        out_splits = recv_counts.tolist()
+        m = int(sum(out_splits))
+        recv = torch.empty((max(m, 1), 2), dtype=torch.int64, device=dev)
+        self._a2a(recv[:m], staged[:n], out_splits, in_splits)
+        return recv, m
+
+    def _a2a(self, out, inp, out_splits, in_splits):
+        """all_to_all_single; with a backend that cannot move device memory (gloo rehearsal of the
+        multi-rank path on a single-GPU box) the payload is staged through host memory."""
+        if inp.is_cuda and dist.get_backend(self.group) == "gloo":
+            h_in, h_out = inp.cpu(), torch.empty(out.shape, dtype=out.dtype)
+            dist.all_to_all_single(h_out, h_in, out_splits, in_splits, group=self.group)
+            out.copy_(h_out)
+        else:
+            dist.all_to_all_single(out, inp, out_splits, in_splits, group=self.group)
+
+    def join(self, R, nR, S, nS, out=None):
+        """Local shards in, local share of the result out: (count, [count,2] tensor of {rowR,rowS})."""
+        Rx, mR = self.exchange(R, nR)
+        Sx, mS = self.exchange(S, nS)
+        self.stats = {"recv_R": mR, "recv_S": mS}
+        cap = out.shape[0] if out is not None else max(mR, mS) + 1024
+        if out is None:
+            out = torch.empty((cap, 2), dtype=torch.int64, device=R.device)
+        cnt = self.engine.join_dev(Rx, mR, Sx, mS, out, cap, opts=self.local_opts, allow_overflow=True)
+        if cnt > cap:                              # more pairs than guessed: exact size is known now
+            out = torch.empty((cnt, 2), dtype=torch.int64, device=R.device)
+            cnt = self.engine.join_dev(Rx, mR, Sx, mS, out, cnt, opts=self.local_opts)
+        return cnt, out

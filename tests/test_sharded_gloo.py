@@ -1,0 +1,107 @@
+"""CPU suite, world_size 2 and 4 over gloo: the multi-GPU driver's exchange logic
+(radixhashjoin_amd/sharded.py).  The ranks have no GPU here, so the engine is replaced by a
+test double whose two operations are restated with numpy / the CPU oracle; what is under test is
+the owner split, the count + tuple all-to-all and the sharded-result contract."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+class OracleEngine:
+    """test double for radixhashjoin_amd.Engine on CPU tensors (duck-typed: partition_at, join_dev)"""
+
+    def __init__(self):
+        from oracle.pyoracle import Oracle
+        self.o = Oracle()
+
+    @staticmethod
+    def _np(t, n):
+        return t.numpy()[:n]
+
+    def partition_at(self, d_in, n, shift, bits, d_out, d_part_start):
+        a = self._np(d_in, n)
+        dig = ((a[:, 1].astype(np.uint64) >> np.uint64(shift)) & np.uint64((1 << bits) - 1)).astype(np.int64)
+        order = np.argsort(dig, kind="stable")
+        d_out.numpy()[:n] = a[order]
+        d_part_start.numpy()[:] = np.concatenate([[0], np.cumsum(np.bincount(dig, minlength=1 << bits))])
+
+    def join_dev(self, d_R, nR, d_S, nS, d_out=None, capacity=0, opts=None, allow_overflow=False):
+        from oracle.pyoracle import TUPLE
+        R = np.ascontiguousarray(self._np(d_R, nR)).view(np.uint64).reshape(-1, 2)
+        S = np.ascontiguousarray(self._np(d_S, nS)).view(np.uint64).reshape(-1, 2)
+        Rt = np.empty(nR, dtype=TUPLE); Rt["key"], Rt["payload"] = R[:, 0], R[:, 1]
+        St = np.empty(nS, dtype=TUPLE); St["key"], St["payload"] = S[:, 0], S[:, 1]
+        p = self.o.join(Rt, St)
+        k = min(len(p), capacity)
+        if d_out is not None and k:
+            d_out.numpy()[:k, 0] = p["keyR"][:k].view(np.int64)
+            d_out.numpy()[:k, 1] = p["keyS"][:k].view(np.int64)
+        return len(p)
+
+
+def worker(rank, world, port, n_per_rank, dup, q):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from oracle.pyoracle import Oracle
+    from radixhashjoin_amd.sharded import ShardedJoin
+    o = Oracle()
+    nglob = n_per_rank * world
+    D = max(nglob // dup, 1)
+    Rg, Sg = o.gen_R(nglob, D), o.gen_S_counter(nglob, D, 42)       # global relations, rows range-sharded
+    lo, hi = rank * n_per_rank, (rank + 1) * n_per_rank
+
+    def shard(t):
+        a = np.empty((hi - lo, 2), dtype=np.uint64)
+        a[:, 0], a[:, 1] = t["key"][lo:hi], t["payload"][lo:hi]
+        return torch.from_numpy(a.view(np.int64))
+
+    sj = ShardedJoin(OracleEngine(), dist.group.WORLD)
+    cnt, out = sj.join(shard(Rg), n_per_rank, shard(Sg), n_per_rank)
+    pairs = out.numpy()[:cnt].view(np.uint64)
+    # every pair this rank produced belongs to its owner class
+    own = (Rg["payload"][pairs[:, 0].astype(np.int64)] >> np.uint64(sj.owner_shift)) & np.uint64(world - 1)
+    assert np.all(own == rank)
+    gathered = [None] * world
+    dist.all_gather_object(gathered, pairs)
+    if rank == 0:
+        allp = np.concatenate(gathered)
+        exp = o.join(Rg, Sg)
+        a = allp[np.lexsort((allp[:, 1], allp[:, 0]))]
+        e = np.stack([exp["keyR"], exp["keyS"]], axis=1)
+        e = e[np.lexsort((e[:, 1], e[:, 0]))]
+        q.put((len(allp), len(exp), bool(np.array_equal(a, e)), sj.stats))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+@pytest.mark.parametrize("world,n_per_rank,dup", [(2, 20_000, 1), (2, 5_000, 4), (4, 6_000, 2)])
+def test_sharded_join_equals_global_join(world, n_per_rank, dup):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = free_port()
+    procs = [ctx.Process(target=worker, args=(r, world, port, n_per_rank, dup, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got, exp, same, stats = q.get(timeout=180)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert got == exp and same

@@ -93,8 +93,11 @@ def main():
             dist.init_process_group(backend)
 
     rdev = dev if (dist is None or dist.get_backend() == "nccl") else torch.device("cpu")
+    # one explicit (non-null) stream shared by torch ops, RCCL hand-offs and the engine's kernels
+    stream = torch.cuda.Stream(device=dev)
+    torch.cuda.set_stream(stream)
     eng = rhj.Engine(local_rank)
-    eng.set_stream(torch.cuda.current_stream().cuda_stream)
+    eng.set_stream(stream.cuda_stream)
     n = args.tuples
     nglobal = n * world
     opts = rhj.Opts(2, args.bits1, args.bits2)

@@ -48,7 +48,9 @@ class ShardedJoin:
             return rel, n
         staged = torch.empty((max(n, 1), 2), dtype=torch.int64, device=dev)
         bounds = torch.empty(self.world + 1, dtype=torch.int64, device=dev)
+        self._fence_torch(dev)                    # rel / buffers produced by torch ops are complete
         self.engine.partition_at(rel, n, self.owner_shift, self.owner_bits, staged, bounds)
+        self._fence_engine()                      # staged / bounds complete before torch and RCCL touch them
         send_counts = (bounds[1:] - bounds[:-1]).contiguous()
         recv_counts = torch.empty_like(send_counts)
         self._a2a(recv_counts, send_counts, None, None)
@@ -58,6 +60,17 @@ class ShardedJoin:
         recv = torch.empty((max(m, 1), 2), dtype=torch.int64, device=dev)
         self._a2a(recv[:m], staged[:n], out_splits, in_splits)
         return recv, m
+
+    # The engine launches on its own HIP stream unless it was given torch's (rhj_set_stream); these two
+    # host-side fences make the hand-offs correct either way.  They cost microseconds per join.
+    def _fence_torch(self, dev):
+        if dev.type == "cuda":
+            torch.cuda.current_stream(dev).synchronize()
+
+    def _fence_engine(self):
+        sync = getattr(self.engine, "sync", None)
+        if sync is not None:
+            sync()
 
     def _a2a(self, out, inp, out_splits, in_splits):
         """all_to_all_single; with a backend that cannot move device memory (gloo rehearsal of the
@@ -77,6 +90,7 @@ class ShardedJoin:
         cap = out.shape[0] if out is not None else max(mR, mS) + 1024
         if out is None:
             out = torch.empty((cap, 2), dtype=torch.int64, device=R.device)
+        self._fence_torch(R.device)               # the received tuples have landed (collective complete)
         cnt = self.engine.join_dev(Rx, mR, Sx, mS, out, cap, opts=self.local_opts, allow_overflow=True)
         if cnt > cap:                              # more pairs than guessed: exact size is known now
             out = torch.empty((cnt, 2), dtype=torch.int64, device=R.device)

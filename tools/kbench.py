@@ -19,6 +19,7 @@ ap.add_argument("--passes", type=int, default=2)
 ap.add_argument("--reps", type=int, default=3)
 ap.add_argument("--dist", default="uniform")
 ap.add_argument("--label", default="")
+ap.add_argument("--probe-split", type=int, default=0)
 ap.add_argument("--no-join", action="store_true", help="partition stage only (safe for ablations that corrupt outputs)")
 a = ap.parse_args()
 
@@ -28,7 +29,7 @@ dR, dS, dO = e.alloc(16 * n), e.alloc(16 * n), e.alloc(16 * n)
 e.generate(GEN_R, dR, n, 0, n)
 e.generate(GEN_S_ZIPF if a.dist == "zipf" else GEN_S_UNIFORM, dS, n, 0, n, seed=42, theta_milli=900)
 exp = e.expected_pkfk(dS, n)
-opts = rhj.Opts(a.passes, a.bits1, a.bits2 if a.passes == 2 else 0)
+opts = rhj.Opts(a.passes, a.bits1, a.bits2 if a.passes == 2 else 0, a.probe_split)
 if a.no_join:
     dP = e.alloc(8 * ((1 << (a.bits1 + (a.bits2 if a.passes == 2 else 0))) + 1))
     e.partition(dR, n, a.bits1, a.bits2 if a.passes == 2 else 0, dO, dP)
@@ -54,6 +55,7 @@ for _ in range(a.reps):
         acc.setdefault(k, [0.0, 0])
         acc[k][0] += t[k]["ms"]; acc[k][1] += t[k]["launches"]
     acc.setdefault("total", [0.0, 0]); acc["total"][0] += t["total_ms"]; acc["total"][1] += 1
+    ntasks = t["ntasks"]
 ok = (cnt, e.pairs_checksum(dO, cnt)) == exp
 per = {k: v[0] / max(v[1], 1) for k, v in acc.items()}
 res = {"label": a.label or os.environ.get("RHJ_VARIANT", ""), "n": n, "bits": [a.bits1, a.bits2], "ok": ok,
@@ -61,5 +63,5 @@ res = {"label": a.label or os.environ.get("RHJ_VARIANT", ""), "n": n, "bits": [a
        "scatter_ms": round(per["scatter"], 3), "scatter_GBs(32B/t)": round(32 * n / per["scatter"] / 1e6, 0) if per["scatter"] else 0,
        "scan_ms": round(per["scan"], 3),
        "join_ms": round(per["join"], 3), "join_GBs(48B/t)": round(48 * n / per["join"] / 1e6, 0),
-       "total_ms": round(per["total"], 3), "Mtuples/s": round(2 * n / per["total"] / 1e3, 0)}
+       "ntasks": ntasks, "total_ms": round(per["total"], 3), "Mtuples/s": round(2 * n / per["total"] / 1e3, 0)}
 print(json.dumps(res))

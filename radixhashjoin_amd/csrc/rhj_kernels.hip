@@ -871,6 +871,15 @@ k_join(const Tup *__restrict__ R, const u64 *__restrict__ startR, const Tup *__r
 //     than one match (foreign-key case), a shuffle scan otherwise; one 64-lane scan over the
 //     (slot, wavefront) totals; one global atomicAdd per 4096-tuple probe tile reserves the pairs.
 // ------------------------------------------------------------------------------------------------
+constexpr u32 BJ_HEAVY = 24;          // bucket length above which a lone lane asks its wavefront for help
+constexpr int BJ_HEAVY_LANES = 16;     // ... unless more than this many lanes of the wavefront are in that position
+
+__device__ __forceinline__ u64 bj_readlane64(u64 v, int srclane)
+{
+    const u32 lo = __builtin_amdgcn_readlane((u32)v, srclane), hi = __builtin_amdgcn_readlane((u32)(v >> 32), srclane);
+    return ((u64)hi << 32) | lo;
+}
+
 __device__ __forceinline__ u32 bj_bucket(u64 v, int radix_bits)
 {
     return (u32)(((v >> radix_bits) * 0x9E3779B97F4A7C15ULL) >> (64 - BJ_BUCKET_BITS));
@@ -965,10 +974,30 @@ k_join_bkt(const Tup *__restrict__ R, const Tup *__restrict__ S, const JoinTask 
             for (int k = 0; k < BJ_EPT; k++) {
                 const u32 i = tb + (u32)k * BJ_THREADS + tid;
                 cnt[k] = 0;
+                u32 lo = 0, hi = 0;
                 if (i < np) {
                     const u32 h = bj_bucket(p[k].payload, radix_bits);
-                    const u32 hi = off[h + 1];
-                    for (u32 j = off[h]; j < hi; j++) cnt[k] += (keys[j] == p[k].payload) ? 1u : 0u;
+                    lo = off[h]; hi = off[h + 1];
+                }
+                // A few lanes facing a long bucket (duplicate-heavy build side, e.g. Zipf FK as build) would
+                // serialise the whole workgroup: those buckets are scanned by all 64 lanes together.
+                unsigned long long heavy = __ballot(hi - lo > BJ_HEAVY);
+                const bool coop = heavy != 0 && __popcll(heavy) <= BJ_HEAVY_LANES;
+                if (!coop || hi - lo <= BJ_HEAVY)
+                    for (u32 j = lo; j < hi; j++) cnt[k] += (keys[j] == p[k].payload) ? 1u : 0u;
+                if (coop) {
+                    while (heavy) {
+                        const int leader = __ffsll((long long)heavy) - 1;
+                        heavy &= heavy - 1;
+                        const u64 key = bj_readlane64(p[k].payload, leader);
+                        const u32 l = __builtin_amdgcn_readlane(lo, leader), hh = __builtin_amdgcn_readlane(hi, leader);
+                        u32 tot = 0;
+                        for (u32 j = l; j < hh; j += 64) {
+                            const bool m = (j + lane < hh) && keys[j + lane] == key;
+                            tot += (u32)__popcll(__ballot(m));
+                        }
+                        if (lane == leader) cnt[k] = tot;
+                    }
                 }
             }
             // per slot: exclusive prefix of the match counts inside the wavefront
@@ -998,11 +1027,16 @@ k_join_bkt(const Tup *__restrict__ R, const Tup *__restrict__ S, const JoinTask 
 #pragma unroll
                 for (int k = 0; k < BJ_EPT; k++) {
                     const u32 sbase = __shfl(inc64 - mine, k * NW + w, 64);   // exclusive prefix of (slot k, wave w)
+                    u32 lo = 0, hi = 0;
                     if (cnt[k]) {
-                        u64 o = g + sbase + pre[k];
                         const u32 h = bj_bucket(p[k].payload, radix_bits);
-                        const u32 hi = off[h + 1];
-                        for (u32 j = off[h]; j < hi; j++) {
+                        lo = off[h]; hi = off[h + 1];
+                    }
+                    u64 o = g + sbase + pre[k];
+                    unsigned long long heavy = __ballot(hi - lo > BJ_HEAVY);
+                    const bool coop = heavy != 0 && __popcll(heavy) <= BJ_HEAVY_LANES;
+                    if (cnt[k] && (!coop || hi - lo <= BJ_HEAVY)) {
+                        for (u32 j = lo; j < hi; j++) {
                             if (keys[j] == p[k].payload) {
                                 if (o < out_capacity) {
                                     Pair pr;
@@ -1011,6 +1045,29 @@ k_join_bkt(const Tup *__restrict__ R, const Tup *__restrict__ S, const JoinTask 
                                     out[o] = pr;
                                 }
                                 o++;
+                            }
+                        }
+                    }
+                    if (coop) {
+                        const unsigned long long lt = (1ull << lane) - 1ull;
+                        while (heavy) {
+                            const int leader = __ffsll((long long)heavy) - 1;
+                            heavy &= heavy - 1;
+                            const u64 key = bj_readlane64(p[k].payload, leader);
+                            const u64 pkey = bj_readlane64(p[k].key, leader);
+                            u64 ob = bj_readlane64(o, leader);
+                            const u32 l = __builtin_amdgcn_readlane(lo, leader), hh = __builtin_amdgcn_readlane(hi, leader);
+                            for (u32 j = l; j < hh; j += 64) {
+                                const bool m = (j + lane < hh) && keys[j + lane] == key;
+                                const unsigned long long bal = __ballot(m);
+                                const u64 dst = ob + (u64)__popcll(bal & lt);
+                                if (m && dst < out_capacity) {
+                                    Pair pr;
+                                    if (build_is_S) { pr.r = pkey; pr.s = rids[j + lane]; }
+                                    else            { pr.r = rids[j + lane]; pr.s = pkey; }
+                                    out[dst] = pr;
+                                }
+                                ob += (u64)__popcll(bal);
                             }
                         }
                     }

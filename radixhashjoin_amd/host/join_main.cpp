@@ -1,0 +1,40 @@
+// join_main.cpp -- the reference's CLI protocol (join.cpp:11-62) on the GPU engine:
+//   stdin = relation file paths, "Done", then batches of queries separated by lines "F";
+//   stdout = one line of SUMs (or NULLs) per query, in input order.
+//   cd tests/golden && cat small/small.init small/small.work | ../../radixhashjoin_amd/host/join_gpu
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <iostream>
+#include <string>
+#include <vector>
+
+#include "rhj_query.h"
+
+int main()
+{
+    std::vector<relList> relations;
+    std::string line;
+    while (std::getline(std::cin, line) && line != "Done") {
+        if (line.empty()) continue;
+        std::vector<char> path(line.begin(), line.end());
+        path.push_back('\0');
+        relations.emplace_back(path.data());
+    }
+    std::vector<std::vector<Query> > batches(1);
+    while (std::getline(std::cin, line)) {
+        if (line.empty()) continue;
+        if (line == "F") { if (!batches.back().empty()) batches.emplace_back(); continue; }
+        batches.back().emplace_back(line);
+    }
+    MainScheduler ms;
+    ms.init(NUM_OF_THREADS);                 // 8 query threads, each with a private JobScheduler = private GPU context
+    for (auto &batch : batches)
+        for (Query &q : batch) ms.schedule(new QueryJob(q, relations));
+    ms.stop();
+    ms.destroy();
+    for (auto &batch : batches)
+        for (const Query &q : batch) q.print();
+    for (relList &r : relations) r.destroy();
+    return 0;
+}

@@ -1,9 +1,24 @@
 // rhj_compat.cpp -- implementation of the reference-surface mirror (rhj_compat.h) over the C-ABI.
 #include "rhj_compat.h"
 
+#include <condition_variable>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
+#include <queue>
+#include <thread>
+
+// n host threads, each owning a private JobScheduler (= a private rhj_ctx): the reference's
+// mainThreadWork (MainScheduler.cpp:6-14) with std::thread instead of pthreads.
+struct WorkerPool {
+    std::mutex mu;
+    std::condition_variable cv_work, cv_idle;
+    std::queue<Job *> q;
+    std::vector<std::thread> threads;
+    size_t busy = 0;
+    bool done = false;
+};
 
 namespace {
 
@@ -49,8 +64,50 @@ bool JobScheduler::init(size_t n)
     return true;
 }
 
+bool JobScheduler::start_query_threads(size_t n)
+{
+    num_of_threads = n;
+    pool_ = new WorkerPool();
+    for (size_t i = 0; i < n; i++) {
+        pool_->threads.emplace_back([this]() {
+            JobScheduler mine;                        // private scheduler = private GPU context
+            mine.init(NUM_OF_THREADS);
+            WorkerPool &p = *pool_;
+            for (;;) {
+                Job *job = nullptr;
+                {
+                    std::unique_lock<std::mutex> lk(p.mu);
+                    p.cv_work.wait(lk, [&] { return p.done || !p.q.empty(); });
+                    if (p.q.empty()) break;           // done and drained
+                    job = p.q.front();
+                    p.q.pop();
+                    p.busy++;
+                }
+                job->gpu = mine.context();
+                job->init(&mine);                     // QueryJob::init receives its private JobScheduler
+                job->run();
+                delete job;
+                {
+                    std::lock_guard<std::mutex> lk(p.mu);
+                    p.busy--;
+                    if (p.q.empty() && p.busy == 0) p.cv_idle.notify_all();
+                }
+            }
+            mine.stop();
+            mine.destroy();
+        });
+    }
+    return true;
+}
+
 int JobScheduler::schedule(Job *job)
 {
+    if (pool_) {
+        std::lock_guard<std::mutex> lk(pool_->mu);
+        pool_->q.push(job);
+        pool_->cv_work.notify_one();
+        return 0;
+    }
     job->gpu = ctx_;
     job->init(job_arg_);
     job->run();
@@ -60,15 +117,34 @@ int JobScheduler::schedule(Job *job)
 
 void JobScheduler::barrier()
 {
+    if (pool_) {
+        std::unique_lock<std::mutex> lk(pool_->mu);
+        pool_->cv_idle.wait(lk, [&] { return pool_->q.empty() && pool_->busy == 0; });
+        return;
+    }
     if (!ctx_) return;
     int rc = rhj_sync(ctx_);
     if (rc != RHJ_OK) die(ctx_, "rhj_sync", rc);
 }
 
-void JobScheduler::stop() { barrier(); }
+void JobScheduler::stop()
+{
+    if (pool_) {                                      // finish every queued job, then join the threads
+        {
+            std::lock_guard<std::mutex> lk(pool_->mu);
+            pool_->done = true;
+        }
+        pool_->cv_work.notify_all();
+        for (std::thread &t : pool_->threads) t.join();
+        pool_->threads.clear();
+        return;
+    }
+    barrier();
+}
 
 bool JobScheduler::destroy()
 {
+    if (pool_) { delete pool_; pool_ = nullptr; }
     if (ctx_) rhj_destroy(ctx_);
     ctx_ = nullptr;
     return true;

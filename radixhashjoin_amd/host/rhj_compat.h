@@ -24,6 +24,9 @@
 
 #include <cstddef>
 #include <cstdint>
+#include <unordered_map>
+#include <unordered_set>
+#include <vector>
 
 #include "../../include/rhj.h"
 
@@ -33,7 +36,9 @@
 
 struct relation;
 struct relation_info;
+struct relList;
 struct Result;
+struct WorkerPool;
 
 /* ---------------------------------------------------------------- JobScheduler.h surface ---------- */
 
@@ -50,6 +55,9 @@ class JobScheduler {                          /* JobScheduler.h:87-124 */
     rhj_ctx *ctx_ = nullptr;
     size_t num_of_threads = 0;
     void *job_arg_ = nullptr;                 /* what Job::init receives (the reference passes threadWork's argument) */
+protected:
+    WorkerPool *pool_ = nullptr;              /* only MainScheduler: n host threads, each with a private JobScheduler */
+    bool start_query_threads(size_t n);       /* MainScheduler.cpp:6-18 */
 public:
     JobScheduler() = default;
     virtual ~JobScheduler() = default;
@@ -101,9 +109,16 @@ struct tuple {                                /* structs.h:33-36: key = rowID, p
     uint64_t payload;
 };
 
-struct relation {                             /* structs.h:38-49 (create_relation / foo belong to the query layer) */
+struct relation {                             /* structs.h:38-49 */
     tuple *tuples;
     uint64_t num_tuples;
+    /* query-layer side of the boundary (rhj_query.cpp): build the AoS input of a join from the filtered
+       rowIDs of an alias or, once the alias is part of the intermediate, from its DISTINCT rowIDs
+       (structs.cpp:217-243) */
+    void create_relation(uint64_t join_table, relList &rel, uint64_t column_number,
+                         std::unordered_map<uint64_t, std::unordered_set<uint64_t> > &filtered,
+                         std::vector<uint64_t> &inter);
+    void foo(const relList &rel, size_t column_number, const std::unordered_set<uint64_t> &uniqueValues);
     ~relation();                              /* delete[] tuples, structs.cpp:210-212 */
 };
 

@@ -317,8 +317,12 @@ int join_phase_on(rhj_ctx *ctx, const void *d_Rp, const u64 *d_psR, u64 nR, cons
     }
     {
         Span s(ctx, RHJ_K_JOIN);
+        // average build partition larger than one 4224-tuple table (an explicit plan with too few bits,
+        // or heavy duplication): the one-workgroup-per-CU geometry with 8448-tuple tables re-probes half as often
+        const u64 nbuild = nR < nS ? nR : nS;
+        const bool big_tables = nbuild / nparts > (u64)BJ_CHUNK;
         launch_join(ctx->stream, d_Rp, d_psR, d_Sp, d_psS, (const JoinTask *)ctx->tasks.p, d_ntasks, max_tasks,
-                    radix_bits, d_out, d_out ? cap : 0, d_count);
+                    radix_bits, d_out, d_out ? cap : 0, d_count, big_tables);
     }
     RHJCHK(check_launch(ctx, "join phase"));
     u64 host[2] = {0, 0};

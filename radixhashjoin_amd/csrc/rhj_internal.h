@@ -66,7 +66,7 @@ void launch_make_tasks(hipStream_t st, const u64 *d_startR, const u64 *d_startS,
                        JoinTask *d_tasks, u32 *d_ntasks, u32 max_tasks);
 void launch_join(hipStream_t st, const void *d_R, const u64 *d_startR, const void *d_S, const u64 *d_startS,
                  const JoinTask *d_tasks, const u32 *d_ntasks, u32 grid, int radix_bits,
-                 void *d_out, u64 out_capacity, u64 *d_out_count);
+                 void *d_out, u64 out_capacity, u64 *d_out_count, bool big_tables);
 void launch_checksum(hipStream_t st, const void *d_pairs, u64 n, u64 *d_sum);
 void launch_generate(hipStream_t st, int kind, void *d_out, u64 n, u64 row0, u64 D, u64 seed, double theta);
 void launch_expected_pkfk(hipStream_t st, const void *d_S, u64 n, u64 *d_sum);

@@ -880,24 +880,32 @@ __device__ __forceinline__ u64 bj_readlane64(u64 v, int srclane)
     return ((u64)hi << 32) | lo;
 }
 
+template <int BBITS>
 __device__ __forceinline__ u32 bj_bucket(u64 v, int radix_bits)
 {
-    return (u32)(((v >> radix_bits) * 0x9E3779B97F4A7C15ULL) >> (64 - BJ_BUCKET_BITS));
+    return (u32)(((v >> radix_bits) * 0x9E3779B97F4A7C15ULL) >> (64 - BBITS));
 }
 
-__global__ void __launch_bounds__(BJ_THREADS, 4)
+// Two geometries of the same kernel:
+//   <512, 4224, 11, 8>   two workgroups per CU (76 KiB LDS each): partitions that fit one table (the planned case)
+//   <1024, 8448, 12, 4>  one workgroup per CU (152 KiB LDS): used when the AVERAGE build partition exceeds 4224 tuples
+//                        (explicit plans such as 8+8 bits at 10^9 tuples): half as many build chunks, so half as
+//                        many re-probes of the probe side
+template <int THREADS, int CHUNK, int BBITS, int EPT>
+__global__ void __launch_bounds__(THREADS, 4)
 k_join_bkt(const Tup *__restrict__ R, const Tup *__restrict__ S, const JoinTask *__restrict__ tasks,
            const u32 *__restrict__ ntasks, int radix_bits, Pair *__restrict__ out, u64 out_capacity,
            u64 *__restrict__ out_count)
 {
-    constexpr int NB = 1 << BJ_BUCKET_BITS;
-    constexpr int NW = BJ_THREADS / 64;
-    constexpr int BPT = (BJ_CHUNK + BJ_THREADS - 1) / BJ_THREADS;            // build tuples per thread
-    static_assert(BJ_EPT * NW == 64, "the (slot, wavefront) totals are scanned by one 64-lane wavefront");
+    constexpr int NB = 1 << BBITS;
+    constexpr int NW = THREADS / 64;
+    constexpr int TILE = THREADS * EPT;
+    constexpr int BPT = (CHUNK + THREADS - 1) / THREADS;            // build tuples per thread
+    static_assert(EPT * NW == 64, "the (slot, wavefront) totals are scanned by one 64-lane wavefront");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    u64 *keys = reinterpret_cast<u64 *>(smem);                               // BJ_CHUNK * 8
-    u64 *rids = keys + BJ_CHUNK;                                             // BJ_CHUNK * 8
-    u32 *off = reinterpret_cast<u32 *>(rids + BJ_CHUNK);                     // NB + 1 (+ pad to 16 B)
+    u64 *keys = reinterpret_cast<u64 *>(smem);                               // CHUNK * 8
+    u64 *rids = keys + CHUNK;                                             // CHUNK * 8
+    u32 *off = reinterpret_cast<u32 *>(rids + CHUNK);                     // NB + 1 (+ pad to 16 B)
     u32 *wtot = off + NB + 4;                                                // 64: [slot][wave] match totals
     u32 *wsum = wtot + 64;                                                   // NW scan scratch
     u64 *gres = reinterpret_cast<u64 *>(wsum + NW);                          // 1
@@ -912,48 +920,48 @@ k_join_bkt(const Tup *__restrict__ R, const Tup *__restrict__ S, const JoinTask 
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
 
     // first probe tile: in flight while the table is built
-    Tup p[BJ_EPT];
+    Tup p[EPT];
 #pragma unroll
-    for (int k = 0; k < BJ_EPT; k++) {
-        const u32 i = (u32)k * BJ_THREADS + tid;
+    for (int k = 0; k < EPT; k++) {
+        const u32 i = (u32)k * THREADS + tid;
         if (i < np) p[k] = P[i];
     }
 
-    for (u32 cb = 0; cb < nb; cb += BJ_CHUNK) {
-        const u32 nc = (nb - cb < (u32)BJ_CHUNK) ? nb - cb : (u32)BJ_CHUNK;
+    for (u32 cb = 0; cb < nb; cb += CHUNK) {
+        const u32 nc = (nb - cb < (u32)CHUNK) ? nb - cb : (u32)CHUNK;
         // ---- build: counting sort of the chunk by hash bucket ---------------------------------
-        for (u32 h = tid; h <= NB; h += BJ_THREADS) off[h] = 0;
+        for (u32 h = tid; h <= NB; h += THREADS) off[h] = 0;
         Tup bt[BPT];
         u32 br[BPT];
 #pragma unroll
         for (int k = 0; k < BPT; k++) {
-            const u32 i = (u32)k * BJ_THREADS + tid;
+            const u32 i = (u32)k * THREADS + tid;
             if (i < nc) bt[k] = B[cb + i];
         }
         __syncthreads();
 #pragma unroll
         for (int k = 0; k < BPT; k++) {
-            const u32 i = (u32)k * BJ_THREADS + tid;
-            if (i < nc) br[k] = atomicAdd(&off[bj_bucket(bt[k].payload, radix_bits)], 1u);
+            const u32 i = (u32)k * THREADS + tid;
+            if (i < nc) br[k] = atomicAdd(&off[bj_bucket<BBITS>(bt[k].payload, radix_bits)], 1u);
         }
         __syncthreads();
-        {   // in-place exclusive scan of the NB bucket counts (NB / BJ_THREADS consecutive buckets per thread)
-            constexpr int PER = NB / BJ_THREADS;
+        {   // in-place exclusive scan of the NB bucket counts (NB / THREADS consecutive buckets per thread)
+            constexpr int PER = NB / THREADS;
             u32 c[PER], loc = 0;
 #pragma unroll
             for (int j = 0; j < PER; j++) { c[j] = off[tid * PER + j]; loc += c[j]; }
             u32 tot;
-            u32 ex = block_excl_scan<BJ_THREADS>(loc, wsum, tot);
+            u32 ex = block_excl_scan<THREADS>(loc, wsum, tot);
 #pragma unroll
             for (int j = 0; j < PER; j++) { off[tid * PER + j] = ex; ex += c[j]; }
-            if (tid == BJ_THREADS - 1) off[NB] = ex;
+            if (tid == THREADS - 1) off[NB] = ex;
         }
         __syncthreads();
 #pragma unroll
         for (int k = 0; k < BPT; k++) {
-            const u32 i = (u32)k * BJ_THREADS + tid;
+            const u32 i = (u32)k * THREADS + tid;
             if (i < nc) {
-                const u32 pos = off[bj_bucket(bt[k].payload, radix_bits)] + br[k];
+                const u32 pos = off[bj_bucket<BBITS>(bt[k].payload, radix_bits)] + br[k];
                 keys[pos] = bt[k].payload;
                 rids[pos] = bt[k].key;
             }
@@ -961,22 +969,22 @@ k_join_bkt(const Tup *__restrict__ R, const Tup *__restrict__ S, const JoinTask 
         __syncthreads();
 
         // ---- probe ------------------------------------------------------------------------------
-        for (u32 tb = 0; tb < np; tb += BJ_TILE) {
+        for (u32 tb = 0; tb < np; tb += TILE) {
             if (tb != 0 || cb != 0) {
 #pragma unroll
-                for (int k = 0; k < BJ_EPT; k++) {
-                    const u32 i = tb + (u32)k * BJ_THREADS + tid;
+                for (int k = 0; k < EPT; k++) {
+                    const u32 i = tb + (u32)k * THREADS + tid;
                     if (i < np) p[k] = P[i];
                 }
             }
-            u32 cnt[BJ_EPT], pre[BJ_EPT];
+            u32 cnt[EPT], pre[EPT];
 #pragma unroll
-            for (int k = 0; k < BJ_EPT; k++) {
-                const u32 i = tb + (u32)k * BJ_THREADS + tid;
+            for (int k = 0; k < EPT; k++) {
+                const u32 i = tb + (u32)k * THREADS + tid;
                 cnt[k] = 0;
                 u32 lo = 0, hi = 0;
                 if (i < np) {
-                    const u32 h = bj_bucket(p[k].payload, radix_bits);
+                    const u32 h = bj_bucket<BBITS>(p[k].payload, radix_bits);
                     lo = off[h]; hi = off[h + 1];
                 }
                 // A few lanes facing a long bucket (duplicate-heavy build side, e.g. Zipf FK as build) would
@@ -1002,7 +1010,7 @@ k_join_bkt(const Tup *__restrict__ R, const Tup *__restrict__ S, const JoinTask 
             }
             // per slot: exclusive prefix of the match counts inside the wavefront
 #pragma unroll
-            for (int k = 0; k < BJ_EPT; k++) {
+            for (int k = 0; k < EPT; k++) {
                 u32 tot;
                 if (__ballot(cnt[k] > 1) == 0) {                              // foreign-key case: ballot + mbcnt
                     const unsigned long long m = __ballot(cnt[k] != 0);
@@ -1025,11 +1033,11 @@ k_join_bkt(const Tup *__restrict__ R, const Tup *__restrict__ S, const JoinTask 
             if (tile_total && out != nullptr) {
                 const u64 g = *gres;
 #pragma unroll
-                for (int k = 0; k < BJ_EPT; k++) {
+                for (int k = 0; k < EPT; k++) {
                     const u32 sbase = __shfl(inc64 - mine, k * NW + w, 64);   // exclusive prefix of (slot k, wave w)
                     u32 lo = 0, hi = 0;
                     if (cnt[k]) {
-                        const u32 h = bj_bucket(p[k].payload, radix_bits);
+                        const u32 h = bj_bucket<BBITS>(p[k].payload, radix_bits);
                         lo = off[h]; hi = off[h + 1];
                     }
                     u64 o = g + sbase + pre[k];
@@ -1165,9 +1173,11 @@ static size_t wc_lds_bytes(int bits)
     return (size_t)WC_TILE * 16 + nbins * (128 + 8 + 8 + 8 + 4 + 4 + 4) + 16 + (WC_THREADS / 64) * 4;
 }
 
-static size_t bj_lds_bytes()
+constexpr int BJ2_THREADS = 1024, BJ2_CHUNK = 8448, BJ2_BUCKET_BITS = 12, BJ2_EPT = 4;
+
+static size_t bj_lds_bytes(int threads, int chunk, int bbits)
 {
-    return (size_t)BJ_CHUNK * 16 + ((size_t)(1 << BJ_BUCKET_BITS) + 4) * 4 + 64 * 4 + (BJ_THREADS / 64) * 4 + 16;
+    return (size_t)chunk * 16 + ((size_t)(1 << bbits) + 4) * 4 + 64 * 4 + (size_t)(threads / 64) * 4 + 16;
 }
 
 size_t join_lds_bytes()
@@ -1187,8 +1197,12 @@ static void allow_big_lds()
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)part_lds_bytes(PART_MAX_BITS));
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_scatter_wc),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)wc_lds_bytes(WC_MAX_BITS));
-    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_join_bkt),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)bj_lds_bytes());
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_join_bkt<BJ_THREADS, BJ_CHUNK, BJ_BUCKET_BITS, BJ_EPT>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize,
+                              (int)bj_lds_bytes(BJ_THREADS, BJ_CHUNK, BJ_BUCKET_BITS));
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_join_bkt<BJ2_THREADS, BJ2_CHUNK, BJ2_BUCKET_BITS, BJ2_EPT>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize,
+                              (int)bj_lds_bytes(BJ2_THREADS, BJ2_CHUNK, BJ2_BUCKET_BITS));
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_join),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)join_lds_bytes());
 }
@@ -1269,14 +1283,21 @@ void launch_make_tasks(hipStream_t st, const u64 *d_startR, const u64 *d_startS,
 
 void launch_join(hipStream_t st, const void *d_R, const u64 *d_startR, const void *d_S, const u64 *d_startS,
                  const JoinTask *d_tasks, const u32 *d_ntasks, u32 grid, int radix_bits,
-                 void *d_out, u64 out_capacity, u64 *d_out_count)
+                 void *d_out, u64 out_capacity, u64 *d_out_count, bool big_tables)
 {
     if (grid == 0) return;
     allow_big_lds();
     static const int variant = getenv("RHJ_JOIN") ? atoi(getenv("RHJ_JOIN")) : 1;
+    if (variant == 1 && !big_tables) {
+        hipLaunchKernelGGL((k_join_bkt<BJ_THREADS, BJ_CHUNK, BJ_BUCKET_BITS, BJ_EPT>), dim3(grid), dim3(BJ_THREADS),
+                           bj_lds_bytes(BJ_THREADS, BJ_CHUNK, BJ_BUCKET_BITS), st, (const Tup *)d_R, (const Tup *)d_S,
+                           d_tasks, d_ntasks, radix_bits, (Pair *)d_out, out_capacity, d_out_count);
+        return;
+    }
     if (variant == 1) {
-        hipLaunchKernelGGL(k_join_bkt, dim3(grid), dim3(BJ_THREADS), bj_lds_bytes(), st, (const Tup *)d_R,
-                           (const Tup *)d_S, d_tasks, d_ntasks, radix_bits, (Pair *)d_out, out_capacity, d_out_count);
+        hipLaunchKernelGGL((k_join_bkt<BJ2_THREADS, BJ2_CHUNK, BJ2_BUCKET_BITS, BJ2_EPT>), dim3(grid), dim3(BJ2_THREADS),
+                           bj_lds_bytes(BJ2_THREADS, BJ2_CHUNK, BJ2_BUCKET_BITS), st, (const Tup *)d_R, (const Tup *)d_S,
+                           d_tasks, d_ntasks, radix_bits, (Pair *)d_out, out_capacity, d_out_count);
         return;
     }
     hipLaunchKernelGGL(k_join, dim3(grid), dim3(JOIN_THREADS), join_lds_bytes(), st, (const Tup *)d_R, d_startR,

@@ -1,0 +1,34 @@
+"""CPU suite: host logic of the C++ mirror that needs no GPU -- query text parser, Result page
+bookkeeping, update_intermediate (3 cases) against a brute-force restatement of the reference's
+semantics (radixhashjoin_amd/host/query_unit.cpp), and the build products exist."""
+import os
+import subprocess
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HOST = os.path.join(ROOT, "radixhashjoin_amd", "host")
+
+
+def test_query_layer_unit_checks():
+    exe = os.path.join(HOST, "query_unit")
+    assert os.path.exists(exe), "build with __graft_entry__.build()"
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stderr
+    assert "all checks passed" in r.stdout
+
+
+def test_host_binaries_built():
+    for name in ("librhj_compat.a", "host_driver", "join_gpu"):
+        assert os.path.exists(os.path.join(HOST, name)), name
+
+
+def test_join_cli_fails_loudly_without_gpu():
+    """no CPU fallback: on a box without a GPU the CLI must exit non-zero with the C-ABI's error"""
+    import radixhashjoin_amd as rhj
+    if rhj.load_library().rhj_device_count() > 0:
+        import pytest
+        pytest.skip("a GPU is present")
+    gold = os.path.join(ROOT, "tests", "golden")
+    stdin = open(os.path.join(gold, "small", "small.init"), "rb").read() + b"3 0|0.2=1.0|1.2\nF\n"
+    r = subprocess.run([os.path.join(HOST, "join_gpu")], input=stdin, cwd=gold, capture_output=True, timeout=120)
+    assert r.returncode != 0
+    assert b"rhj_init failed" in r.stderr

@@ -5,7 +5,7 @@
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
 A "step" is one complete radixHashJoin of the synthetic workload with inputs already resident in
-HBM: partition R, partition S (2 passes of 8+8 radix bits by default, BASELINE config 3), bucket
+HBM: partition R, partition S (2 passes of 8+8 radix bits by default, BASELINE config 3 as named), bucket
 build/probe, result pairs written to HBM, exact result count read back.  Rank 0 prints ONE JSON
 line.  `value` = (|R|+|S|) tuples joined per second, whole job (all ranks).
 
@@ -202,7 +202,7 @@ def main():
                                    f"2-pass ({args.bits1}+{args.bits2} bit) radix, inputs and pairs resident in HBM",
                        "tuples_R_global": nglobal, "tuples_S_global": nglobal, "matches_last_step_rank0": cnt,
                        "exchange": "none (single GPU)" if world == 1 else "RCCL all-to-all by owner radix bits"},
-            "roofline": {"bound": "hbm", "kernel": "k_scatter_units (scatter-partition, one pass of one relation)",
+            "roofline": {"bound": "hbm", "kernel": "k_scatter_wc (line-aligned write-combining scatter-partition, one pass over one relation)",
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": traffic, "algorithmic_bytes_per_launch": SCATTER_BYTES_PER_TUPLE * tuples_per_launch,
                          "avg_launch_ms": sc_ms,

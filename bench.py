@@ -63,7 +63,7 @@ def main():
     ap.add_argument("--bits1", type=int, default=8)
     ap.add_argument("--bits2", type=int, default=8)
     ap.add_argument("--dist", choices=["uniform", "zipf"], default="uniform")
-    ap.add_argument("--cpu-sample", type=int, default=32_000_000, help="rows per side of the CPU baseline sample (0 = skip)")
+    ap.add_argument("--cpu-sample", type=int, default=256_000_000, help="rows per side of the CPU baseline sample (0 = skip)")
     ap.add_argument("--no-verify", action="store_true")
     ap.add_argument("--no-auto", action="store_true", help="skip the extra (untimed-for-value) run under the automatic radix plan")
     args = ap.parse_args()

@@ -63,11 +63,11 @@ for line in open(os.path.join(src, "bench_trace.log")):
         bench = json.loads(line)
 out = {"tag": tag, "bench_line_under_kernel_trace": bench, "kernels": pmc}
 json.dump(out, open(os.path.join(ROOT, "profiles", f"{rnd}_{tag}_pmc.json"), "w"), indent=1)
-if "k_scatter_units" in pmc and "hbm_bytes_per_launch" in pmc["k_scatter_units"]:
+if "k_scatter_wc" in pmc and "hbm_bytes_per_launch" in pmc["k_scatter_wc"]:
     m = re.search(r"^(\d+) x", bench.get("config", {}).get("workload", ""))
     b = re.search(r"\((\d+)\+(\d+) bit\)", bench.get("config", {}).get("workload", ""))
     json.dump({"tuples": int(m.group(1)) if m else None, "bits": [int(b.group(1)), int(b.group(2))] if b else None,
-               "scatter_hbm_bytes_per_launch": pmc["k_scatter_units"]["hbm_bytes_per_launch"],
+               "scatter_hbm_bytes_per_launch": pmc["k_scatter_wc"]["hbm_bytes_per_launch"],
                "source": f"profiles/{rnd}_{tag}_pmc.json"}, open(os.path.join(ROOT, "profiles", "traffic.json"), "w"), indent=1)
 for r in rows[:8]:
     print(f'{short(r["Name"]):28s} calls={r["Calls"]:>4s} avg={float(r["AverageNs"])/1e6:9.3f} ms  {r["Percentage"]}%')

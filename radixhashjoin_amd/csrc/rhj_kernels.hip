@@ -895,7 +895,7 @@ template <int THREADS, int CHUNK, int BBITS, int EPT>
 __global__ void __launch_bounds__(THREADS, 4)
 k_join_bkt(const Tup *__restrict__ R, const Tup *__restrict__ S, const JoinTask *__restrict__ tasks,
            const u32 *__restrict__ ntasks, int radix_bits, Pair *__restrict__ out, u64 out_capacity,
-           u64 *__restrict__ out_count)
+           u64 *__restrict__ out_count, int ablate)
 {
     constexpr int NB = 1 << BBITS;
     constexpr int NW = THREADS / 64;
@@ -969,6 +969,7 @@ k_join_bkt(const Tup *__restrict__ R, const Tup *__restrict__ S, const JoinTask 
         __syncthreads();
 
         // ---- probe ------------------------------------------------------------------------------
+        if (ablate & 4) continue;
         for (u32 tb = 0; tb < np; tb += TILE) {
             if (tb != 0 || cb != 0) {
 #pragma unroll
@@ -1028,10 +1029,10 @@ k_join_bkt(const Tup *__restrict__ R, const Tup *__restrict__ S, const JoinTask 
             const u32 mine = wtot[lane];
             const u32 inc64 = wave_incl_scan(mine, lane);
             const u32 tile_total = __shfl(inc64, 63, 64);
-            if (tid == 0 && tile_total) *gres = atomicAdd(out_count, (u64)tile_total);
+            if (tid == 0 && tile_total) *gres = (ablate & 2) ? (u64)blockIdx.x * 4096 % 900000000ull : atomicAdd(out_count, (u64)tile_total);
             __syncthreads();
-            if (tile_total && out != nullptr) {
-                const u64 g = *gres;
+            if (tile_total && out != nullptr && !(ablate & 1)) {
+                const u64 g = (ablate & 8) ? (*gres & ~7ull) : *gres;
 #pragma unroll
                 for (int k = 0; k < EPT; k++) {
                     const u32 sbase = __shfl(inc64 - mine, k * NW + w, 64);   // exclusive prefix of (slot k, wave w)
@@ -1288,16 +1289,17 @@ void launch_join(hipStream_t st, const void *d_R, const u64 *d_startR, const voi
     if (grid == 0) return;
     allow_big_lds();
     static const int variant = getenv("RHJ_JOIN") ? atoi(getenv("RHJ_JOIN")) : 1;
+    static const int jabl = getenv("RHJ_JABL") ? atoi(getenv("RHJ_JABL")) : 0;      // development ablations
     if (variant == 1 && !big_tables) {
         hipLaunchKernelGGL((k_join_bkt<BJ_THREADS, BJ_CHUNK, BJ_BUCKET_BITS, BJ_EPT>), dim3(grid), dim3(BJ_THREADS),
                            bj_lds_bytes(BJ_THREADS, BJ_CHUNK, BJ_BUCKET_BITS), st, (const Tup *)d_R, (const Tup *)d_S,
-                           d_tasks, d_ntasks, radix_bits, (Pair *)d_out, out_capacity, d_out_count);
+                           d_tasks, d_ntasks, radix_bits, (Pair *)d_out, out_capacity, d_out_count, jabl);
         return;
     }
     if (variant == 1) {
         hipLaunchKernelGGL((k_join_bkt<BJ2_THREADS, BJ2_CHUNK, BJ2_BUCKET_BITS, BJ2_EPT>), dim3(grid), dim3(BJ2_THREADS),
                            bj_lds_bytes(BJ2_THREADS, BJ2_CHUNK, BJ2_BUCKET_BITS), st, (const Tup *)d_R, (const Tup *)d_S,
-                           d_tasks, d_ntasks, radix_bits, (Pair *)d_out, out_capacity, d_out_count);
+                           d_tasks, d_ntasks, radix_bits, (Pair *)d_out, out_capacity, d_out_count, jabl);
         return;
     }
     hipLaunchKernelGGL(k_join, dim3(grid), dim3(JOIN_THREADS), join_lds_bytes(), st, (const Tup *)d_R, d_startR,

@@ -9,7 +9,8 @@ ONE exchange step, an all-to-all of tuples by OWNER RADIX BITS:
   1. every rank splits its shard of R (then S) by owner bits with one scatter-partition pass
      (rhj_partition_at): tuples for rank d become contiguous, d = 0..world-1;
   2. a tiny all-to-all of the per-destination counts, then ONE all_to_all_single of the tuples
-     (RCCL: world-1 direct peer sends over xGMI, all links busy at once, no multi-hop);
+     (RCCL: world-1 direct peer sends over xGMI, all links busy at once, no multi-hop); the
+     exchange of R is in flight while S is being split;
   3. every rank now holds ALL tuples of its owner class of both relations and runs the normal
      single-GPU join (rhj_join_dev: 1-2 radix passes on the low bits + LDS bucket join) locally.
      Owner bits lie above every bit the local plan can use (2 * 10), so the local plan is untouched.
@@ -39,27 +40,68 @@ class ShardedJoin:
         self.local_opts = local_opts
         self.stats = {}
 
-    # -- step 1+2 for one relation: owner split, count exchange, tuple exchange -------------------
-    def exchange(self, rel, n):
-        """rel: [n,2] int64 tensor of {rowID, join value} on this rank's device.
-        Returns (received [m,2] tensor, m): every tuple of the global relation owned by this rank."""
+    # -- step 1: owner split of one shard (compute) ------------------------------------------------
+    def split(self, rel, n):
+        """One scatter-partition pass by owner bits.  Returns (staged [n,2] tensor with each destination's
+        tuples contiguous, per-destination counts as a python list)."""
         dev = rel.device
-        if self.world == 1:
-            return rel, n
         staged = torch.empty((max(n, 1), 2), dtype=torch.int64, device=dev)
         bounds = torch.empty(self.world + 1, dtype=torch.int64, device=dev)
         self._fence_torch(dev)                    # rel / buffers produced by torch ops are complete
         self.engine.partition_at(rel, n, self.owner_shift, self.owner_bits, staged, bounds)
         self._fence_engine()                      # staged / bounds complete before torch and RCCL touch them
-        send_counts = (bounds[1:] - bounds[:-1]).contiguous()
+        return staged, (bounds[1:] - bounds[:-1]).contiguous()
+
+    # -- step 2: count exchange + tuple exchange (communication) ----------------------------------
+    def start_exchange(self, staged, n, send_counts):
+        """Launches the all-to-all of `staged`; returns a handle for finish_exchange.  With RCCL the
+        transfer proceeds on the communicator's stream while the caller keeps launching kernels."""
         recv_counts = torch.empty_like(send_counts)
         self._a2a(recv_counts, send_counts, None, None)
         in_splits = send_counts.tolist()          # host sync: the exchange sizes must be known
         out_splits = recv_counts.tolist()
         m = int(sum(out_splits))
-        recv = torch.empty((max(m, 1), 2), dtype=torch.int64, device=dev)
-        self._a2a(recv[:m], staged[:n], out_splits, in_splits)
+        recv = torch.empty((max(m, 1), 2), dtype=torch.int64, device=staged.device)
+        work = self._a2a(recv[:m], staged[:n], out_splits, in_splits, async_op=True)
+        return recv, m, work, staged              # staged must stay alive until the transfer has finished
+
+    @staticmethod
+    def finish_exchange(handle):
+        recv, m, work, _staged = handle
+        if work is not None:
+            work.wait()
         return recv, m
+
+    def exchange(self, rel, n):
+        """rel: [n,2] int64 tensor of {rowID, join value} on this rank's device.
+        Returns (received [m,2] tensor, m): every tuple of the global relation owned by this rank."""
+        if self.world == 1:
+            return rel, n
+        staged, counts = self.split(rel, n)
+        return self.finish_exchange(self.start_exchange(staged, n, counts))
+
+    def join(self, R, nR, S, nS, out=None):
+        """Local shards in, local share of the result out: (count, [count,2] tensor of {rowR,rowS}).
+        Schedule: split R | exchange R overlapped with split S | exchange S | local join."""
+        if self.world == 1:
+            Rx, mR, Sx, mS = R, nR, S, nS
+        else:
+            stagedR, cR = self.split(R, nR)
+            hR = self.start_exchange(stagedR, nR, cR)          # R tuples on the wire ...
+            stagedS, cS = self.split(S, nS)                    # ... while S is being split
+            hS = self.start_exchange(stagedS, nS, cS)
+            Rx, mR = self.finish_exchange(hR)
+            Sx, mS = self.finish_exchange(hS)
+        self.stats = {"recv_R": mR, "recv_S": mS}
+        cap = out.shape[0] if out is not None else max(mR, mS) + 1024
+        if out is None:
+            out = torch.empty((cap, 2), dtype=torch.int64, device=R.device)
+        self._fence_torch(R.device)               # the received tuples have landed (collective complete)
+        cnt = self.engine.join_dev(Rx, mR, Sx, mS, out, cap, opts=self.local_opts, allow_overflow=True)
+        if cnt > cap:                              # more pairs than guessed: exact size is known now
+            out = torch.empty((cnt, 2), dtype=torch.int64, device=R.device)
+            cnt = self.engine.join_dev(Rx, mR, Sx, mS, out, cnt, opts=self.local_opts)
+        return cnt, out
 
     # The engine launches on its own HIP stream unless it was given torch's (rhj_set_stream); these two
     # host-side fences make the hand-offs correct either way.  They cost microseconds per join.
@@ -72,27 +114,12 @@ class ShardedJoin:
         if sync is not None:
             sync()
 
-    def _a2a(self, out, inp, out_splits, in_splits):
+    def _a2a(self, out, inp, out_splits, in_splits, async_op=False):
         """all_to_all_single; with a backend that cannot move device memory (gloo rehearsal of the
         multi-rank path on a single-GPU box) the payload is staged through host memory."""
         if inp.is_cuda and dist.get_backend(self.group) == "gloo":
             h_in, h_out = inp.cpu(), torch.empty(out.shape, dtype=out.dtype)
             dist.all_to_all_single(h_out, h_in, out_splits, in_splits, group=self.group)
             out.copy_(h_out)
-        else:
-            dist.all_to_all_single(out, inp, out_splits, in_splits, group=self.group)
-
-    def join(self, R, nR, S, nS, out=None):
-        """Local shards in, local share of the result out: (count, [count,2] tensor of {rowR,rowS})."""
-        Rx, mR = self.exchange(R, nR)
-        Sx, mS = self.exchange(S, nS)
-        self.stats = {"recv_R": mR, "recv_S": mS}
-        cap = out.shape[0] if out is not None else max(mR, mS) + 1024
-        if out is None:
-            out = torch.empty((cap, 2), dtype=torch.int64, device=R.device)
-        self._fence_torch(R.device)               # the received tuples have landed (collective complete)
-        cnt = self.engine.join_dev(Rx, mR, Sx, mS, out, cap, opts=self.local_opts, allow_overflow=True)
-        if cnt > cap:                              # more pairs than guessed: exact size is known now
-            out = torch.empty((cnt, 2), dtype=torch.int64, device=R.device)
-            cnt = self.engine.join_dev(Rx, mR, Sx, mS, out, cnt, opts=self.local_opts)
-        return cnt, out
+            return None
+        return dist.all_to_all_single(out, inp, out_splits, in_splits, group=self.group, async_op=async_op)

@@ -43,7 +43,7 @@ struct rhj_ctx {
     DevBuf seg0, unit_start, unit_hist, unit_base;
     DevBuf tasks, counters;            // counters: [0] u64 out_count, [1] u32 ntasks (+pad), [2] u64 checksum
     DevBuf out_pairs;                  // rhj_join's device result buffer
-    DevBuf hist_tmp, scan_tmp;
+    DevBuf hist_tmp, scan_tmp, hist2, grp_rng, unit_start2;
     // state of the last partition phase (consumed by join_phase)
     const void *cur_R = nullptr, *cur_S = nullptr;
     const u64 *cur_psR = nullptr, *cur_psS = nullptr;
@@ -238,9 +238,73 @@ int run_pass(rhj_ctx *ctx, const void *d_in, void *d_out, u64 n, const u64 *d_se
     return check_launch(ctx, "partition pass");
 }
 
+// Two passes with ONE histogram read (k_hist2d_units): used when both passes fit the write-combining scatter
+// and b1 + b2 <= 16.  Pass-2 units = pieces of each pass-1 bucket written by groups of pass-1 units.
+int partition_relation_fused(rhj_ctx *ctx, const void *d_in, u64 n, int b1, int b2, void *d_out, u64 *d_ps)
+{
+    const PassGeom g1 = make_geom(n, 1, 0, b1);
+    const u32 units1 = (u32)((n + g1.L - 1) / g1.L);
+    const u32 want_groups = 16;
+    const u32 per = units1 ? (units1 + want_groups - 1) / want_groups : 1;
+    const u32 ngroups = units1 ? (units1 + per - 1) / per : 1;
+    const size_t nb1 = (size_t)1 << b1, nb2 = (size_t)1 << b2;
+    const u32 units2 = (u32)(nb1 * ngroups);
+    RHJCHK(ensure(ctx, ctx->seg0, 64));
+    RHJCHK(ensure(ctx, ctx->unit_start, 16));
+    RHJCHK(ensure(ctx, ctx->unit_hist, (size_t)(units1 + 1) * nb1 * 4));
+    RHJCHK(ensure(ctx, ctx->unit_base, (size_t)((units1 + 1) * nb1 > units2 * nb2 ? (units1 + 1) * nb1 : units2 * nb2) * 8));
+    RHJCHK(ensure(ctx, ctx->scan_tmp, scan_tmp_bytes(b1)));
+    RHJCHK(ensure(ctx, ctx->hist2, (size_t)units2 * nb2 * 4));
+    RHJCHK(ensure(ctx, ctx->grp_rng, ((size_t)units2 + 1) * 8));
+    RHJCHK(ensure(ctx, ctx->unit_start2, (nb1 + 1) * 4));
+    RHJCHK(ensure(ctx, ctx->part_tmp, (size_t)(n ? n : 1) * 16));
+    RHJCHK(ensure(ctx, ctx->ps_1, (nb1 + 1) * 8));
+    u64 *seg0 = (u64 *)ctx->seg0.p;
+    u32 *unit_start1 = (u32 *)ctx->unit_start.p;
+    {
+        Span s(ctx, RHJ_K_AUX);
+        launch_init_single_segment(ctx->stream, n, g1.L, seg0, unit_start1);          // seg0 = {0,n}, unit_start1 = {0, units1}
+        HIPCHK(ctx, hipMemsetAsync(ctx->hist2.p, 0, (size_t)units2 * nb2 * 4, ctx->stream));
+    }
+    {
+        Span s(ctx, RHJ_K_HIST);
+        launch_hist2d_units(ctx->stream, d_in, n, g1.L, units1, b1, b2, per, ngroups, (u32 *)ctx->unit_hist.p, (u32 *)ctx->hist2.p);
+    }
+    {
+        Span s(ctx, RHJ_K_SCAN);
+        launch_scan_units(ctx->stream, g1, seg0, unit_start1, (const u32 *)ctx->unit_hist.p, (u64 *)ctx->unit_base.p,
+                          (u64 *)ctx->ps_1.p, (u64 *)ctx->scan_tmp.p);
+    }
+    {
+        Span s(ctx, RHJ_K_SCATTER);
+        launch_scatter_units(ctx->stream, d_in, ctx->part_tmp.p, g1, seg0, unit_start1, (const u64 *)ctx->unit_base.p);
+    }
+    {
+        Span s(ctx, RHJ_K_AUX);
+        launch_make_group_ranges(ctx->stream, (const u64 *)ctx->unit_base.p, (u32)nb1, per, ngroups, n, (u64 *)ctx->grp_rng.p,
+                                 (u32 *)ctx->unit_start2.p);
+    }
+    PassGeom g2;
+    g2.n = n; g2.L = 0; g2.nseg = (u32)nb1; g2.max_units = units2; g2.shift = b1; g2.bits = b2;
+    {
+        Span s(ctx, RHJ_K_SCAN);
+        launch_scan_units(ctx->stream, g2, (const u64 *)ctx->ps_1.p, (const u32 *)ctx->unit_start2.p, (const u32 *)ctx->hist2.p,
+                          (u64 *)ctx->unit_base.p, d_ps, nullptr);
+    }
+    {
+        Span s(ctx, RHJ_K_SCATTER);
+        launch_scatter_ranges(ctx->stream, ctx->part_tmp.p, d_out, units2, b1, b2, (const u64 *)ctx->unit_base.p,
+                              (const u64 *)ctx->grp_rng.p);
+    }
+    return check_launch(ctx, "fused two-pass partition");
+}
+
 // Partition one relation with `passes` passes into d_out; boundaries into d_ps[2^(b1+b2) + 1].
 int partition_relation(rhj_ctx *ctx, const void *d_in, u64 n, int passes, int b1, int b2, void *d_out, u64 *d_ps)
 {
+    static const bool fused_enabled = !(getenv("RHJ_FUSED") && atoi(getenv("RHJ_FUSED")) == 0);
+    if (passes == 2 && fused_enabled && fused_two_pass_ok(b1, b2) && n > 0 && n < ((u64)1 << 32))
+        return partition_relation_fused(ctx, d_in, n, b1, b2, d_out, d_ps);
     RHJCHK(ensure(ctx, ctx->seg0, 64));
     u64 *seg0 = (u64 *)ctx->seg0.p;
     {
@@ -401,7 +465,8 @@ int rhj_release_workspace(rhj_ctx *ctx)
     (void)hipStreamSynchronize(ctx->stream);
     DevBuf *all[] = {&ctx->in_R, &ctx->in_S, &ctx->part_R, &ctx->part_S, &ctx->part_tmp, &ctx->ps_R, &ctx->ps_S,
                      &ctx->ps_1, &ctx->seg0, &ctx->unit_start, &ctx->unit_hist, &ctx->unit_base, &ctx->tasks,
-                     &ctx->counters, &ctx->out_pairs, &ctx->hist_tmp, &ctx->scan_tmp};
+                     &ctx->counters, &ctx->out_pairs, &ctx->hist_tmp, &ctx->scan_tmp, &ctx->hist2,
+                     &ctx->grp_rng, &ctx->unit_start2};
     for (DevBuf *b : all) release(*b);
     return RHJ_OK;
 }

@@ -70,6 +70,13 @@ void launch_join(hipStream_t st, const void *d_R, const u64 *d_startR, const voi
 void launch_checksum(hipStream_t st, const void *d_pairs, u64 n, u64 *d_sum);
 void launch_generate(hipStream_t st, int kind, void *d_out, u64 n, u64 row0, u64 D, u64 seed, double theta);
 void launch_expected_pkfk(hipStream_t st, const void *d_S, u64 n, u64 *d_sum);
+bool fused_two_pass_ok(int b1, int b2);
+void launch_hist2d_units(hipStream_t st, const void *d_in, u64 n, u64 L, u32 units, int b1, int b2,
+                         u32 units_per_group, u32 ngroups, u32 *d_hist1, u32 *d_hist2);
+void launch_make_group_ranges(hipStream_t st, const u64 *d_unit_base1, u32 nb1, u32 units_per_group, u32 ngroups, u64 n,
+                              u64 *d_rng, u32 *d_unit_start2);
+void launch_scatter_ranges(hipStream_t st, const void *d_in, void *d_out, u32 nunits, int shift, int bits,
+                           const u64 *d_unit_base, const u64 *d_rng);
 size_t join_lds_bytes();
 size_t scan_tmp_bytes(int bits);
 size_t part_lds_bytes(int bits);

@@ -153,6 +153,90 @@ k_hist_units(const Tup *__restrict__ in, const u64 *__restrict__ seg_start, cons
     for (u32 b = threadIdx.x; b < nbins; b += PART_THREADS) out[b] = cnt[b];
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// K1 (fused two-pass form): ONE read of the input yields the histograms of BOTH passes.
+//   hist1[u][d1]            per pass-1 unit, as k_hist_units
+//   hist2[(d1*NG + g)][d2]  per pass-2 unit: pass-2 units are defined as "the piece of bucket d1 written by
+//                           group g of pass-1 units" (a contiguous range of the pass-1 output whose bounds
+//                           come from the pass-1 cursors), so every tuple's pass-2 unit is known here.
+// The (d1,d2) counts of a unit live in LDS as packed 16-bit counters (2^(b1+b2) x 2 B <= 128 KiB).  A counter
+// is drained to the global table when it reaches 2^15 (the thread whose add moved it from 0x7FFF takes
+// 0x8000 out again), so a half can never carry into its neighbour: at most threads x 4 adds are in flight.
+// Saves the second histogram read: 16 B/tuple of HBM traffic per relation.
+// ------------------------------------------------------------------------------------------------
+constexpr int H2_THREADS = 1024;
+
+__global__ void __launch_bounds__(H2_THREADS)
+k_hist2d_units(const Tup *__restrict__ in, u64 n, u64 L, int b1, int b2, u32 units_per_group, u32 ngroups,
+               u32 *__restrict__ hist1, u32 *__restrict__ hist2)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const u32 nb1 = 1u << b1, nb2 = 1u << b2, nbin = nb1 * nb2;
+    u32 *tab = reinterpret_cast<u32 *>(smem);                 // nbin / 2 words, two 16-bit counters each
+    u32 *sum1 = tab + (nbin >> 1);                            // nb1
+    const u32 u = blockIdx.x;
+    const u64 beg = (u64)u * L;
+    if (beg >= n) return;
+    const u64 end = (beg + L < n) ? beg + L : n;
+    const u32 grp = u / units_per_group;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const u32 m1 = nb1 - 1, m2 = nb2 - 1;
+
+    for (u32 i = tid; i < (nbin >> 1) + nb1; i += H2_THREADS) tab[i] = 0;
+    __syncthreads();
+
+    auto count = [&](u64 payload) {
+        const u32 d1 = (u32)payload & m1, d2 = (u32)(payload >> b1) & m2;
+        const u32 bin = (d1 << b2) | d2, sh = (bin & 1u) * 16u;
+        const u32 old = atomicAdd(&tab[bin >> 1], 1u << sh);
+        if (((old >> sh) & 0xFFFFu) == 0x7FFFu) {             // this add made it 2^15: drain 2^15 to the global tables
+            atomicSub(&tab[bin >> 1], 0x8000u << sh);
+            atomicAdd(&hist2[((u64)(d1 * ngroups + grp) << b2) + d2], 0x8000u);
+            atomicAdd(&sum1[d1], 0x8000u);
+        }
+    };
+    u64 i = beg + tid;
+    for (; i + 3ull * H2_THREADS < end; i += 4ull * H2_THREADS) {
+        const Tup t0 = in[i], t1 = in[i + H2_THREADS], t2 = in[i + 2 * H2_THREADS], t3 = in[i + 3 * H2_THREADS];
+        count(t0.payload); count(t1.payload); count(t2.payload); count(t3.payload);
+    }
+    for (; i < end; i += H2_THREADS) count(in[i].payload);
+    __syncthreads();
+
+    // flush: 64 consecutive bins per wavefront instruction (one 256 B row segment of hist2 when nb2 >= 64)
+    for (u32 bin = tid; bin < nbin; bin += H2_THREADS) {
+        const u32 c = (tab[bin >> 1] >> ((bin & 1u) * 16u)) & 0xFFFFu;
+        const u32 d1 = bin >> b2, d2 = bin & m2;
+        if (c) atomicAdd(&hist2[((u64)(d1 * ngroups + grp) << b2) + d2], c);
+        if (nb2 >= 64) {                                       // whole wavefront shares d1: reduce, one LDS add
+            u32 r = c;
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) r += __shfl_down(r, off, 64);
+            if (lane == 0 && r) atomicAdd(&sum1[d1], r);
+        } else if (c) {
+            atomicAdd(&sum1[d1], c);
+        }
+    }
+    __syncthreads();
+    for (u32 d = tid; d < nb1; d += H2_THREADS) hist1[(u64)u * nb1 + d] = sum1[d];
+}
+
+// rng[d1*NG + g] = first output index of bucket d1 written by group g of pass-1 units (= the pass-1 cursor of
+// the group's first unit); rng[nb1*NG] = n; unit_start2[d1] = d1*NG (NG pass-2 units per bucket).
+__global__ void k_make_group_ranges(const u64 *__restrict__ unit_base1, u32 nb1, u32 units_per_group, u32 ngroups,
+                                    u64 n, u64 *__restrict__ rng, u32 *__restrict__ unit_start2)
+{
+    const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+    const u32 total = nb1 * ngroups;
+    if (i < total) {
+        const u32 d1 = i / ngroups, g = i % ngroups;
+        rng[i] = unit_base1[(u64)g * units_per_group * nb1 + d1];
+    }
+    if (i == total) rng[total] = n;
+    if (i <= nb1) unit_start2[i] = i * ngroups;
+}
+
 // ------------------------------------------------------------------------------------------------
 // K2: per segment, turn unit histograms into absolute write cursors.
 //   part_start[s*nbins + d] = seg_start[s] + sum_{d'<d} total(s,d')         (the global histogram's
@@ -501,7 +585,7 @@ constexpr int WC_MAX_BITS = 9;
 __global__ void __launch_bounds__(WC_THREADS)
 k_scatter_wc(const Tup *__restrict__ in, Tup *__restrict__ out, const u64 *__restrict__ seg_start,
              const u32 *__restrict__ unit_start, u32 nseg, u64 L, int shift, int bits,
-             const u64 *__restrict__ unit_base)
+             const u64 *__restrict__ unit_base, const u64 *__restrict__ unit_rng, u32 n_rng_units)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const u32 nbins = 1u << bits, mask = nbins - 1;
@@ -517,11 +601,18 @@ k_scatter_wc(const Tup *__restrict__ in, Tup *__restrict__ out, const u64 *__res
     u32 *wsc = mtot + 4;                                                     // WC_THREADS/64 wave totals
 
     const u32 u = blockIdx.x;
-    if (u >= unit_start[nseg]) return;
-    const u32 s = find_segment(unit_start, nseg, u);
-    const u64 beg = seg_start[s] + (u64)(u - unit_start[s]) * L;
-    const u64 send = seg_start[s + 1];
-    const u64 end = (beg + L < send) ? beg + L : send;
+    u64 beg, end;
+    if (unit_rng != nullptr) {               // explicit unit ranges (fused two-pass plan: units of pass 2 are
+        if (u >= n_rng_units) return;        // the pieces of a bucket written by groups of pass-1 units)
+        beg = unit_rng[u];
+        end = unit_rng[u + 1];
+    } else {
+        if (u >= unit_start[nseg]) return;
+        const u32 s = find_segment(unit_start, nseg, u);
+        beg = seg_start[s] + (u64)(u - unit_start[s]) * L;
+        const u64 send = seg_start[s + 1];
+        end = (beg + L < send) ? beg + L : send;
+    }
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
 
     for (u32 b = tid; b < nbins; b += WC_THREADS) {
@@ -1251,7 +1342,7 @@ void launch_scatter_units(hipStream_t st, const void *d_in, void *d_out, const P
     if (variant == 2 && g.bits <= WC_MAX_BITS) {
         hipLaunchKernelGGL(k_scatter_wc, dim3(g.max_units), dim3(WC_THREADS), wc_lds_bytes(g.bits), st,
                            (const Tup *)d_in, (Tup *)d_out, d_seg_start, d_unit_start, g.nseg, g.L, g.shift, g.bits,
-                           d_unit_base);
+                           d_unit_base, (const u64 *)nullptr, 0u);
         return;
     }
     if (variant >= 1) {
@@ -1263,6 +1354,40 @@ void launch_scatter_units(hipStream_t st, const void *d_in, void *d_out, const P
     hipLaunchKernelGGL(k_scatter_units, dim3(g.max_units), dim3(PART_THREADS), part_lds_bytes(g.bits), st,
                        (const Tup *)d_in, (Tup *)d_out, d_seg_start, d_unit_start, g.nseg, g.L, g.shift, g.bits,
                        d_unit_base, getenv("RHJ_ABLATE") ? atoi(getenv("RHJ_ABLATE")) : 0);
+}
+
+bool fused_two_pass_ok(int b1, int b2) { return b1 >= 1 && b2 >= 1 && b1 <= WC_MAX_BITS && b2 <= WC_MAX_BITS && b1 + b2 <= 16; }
+
+void launch_hist2d_units(hipStream_t st, const void *d_in, u64 n, u64 L, u32 units, int b1, int b2,
+                         u32 units_per_group, u32 ngroups, u32 *d_hist1, u32 *d_hist2)
+{
+    static bool once = false;
+    const size_t lds = ((size_t)1 << (b1 + b2)) * 2 + ((size_t)4 << b1);
+    if (!once) {
+        once = true;
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_hist2d_units),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)(((size_t)1 << 16) * 2 + ((size_t)4 << WC_MAX_BITS)));
+    }
+    if (units == 0) return;
+    hipLaunchKernelGGL(k_hist2d_units, dim3(units), dim3(H2_THREADS), lds, st, (const Tup *)d_in, n, L, b1, b2,
+                       units_per_group, ngroups, d_hist1, d_hist2);
+}
+
+void launch_make_group_ranges(hipStream_t st, const u64 *d_unit_base1, u32 nb1, u32 units_per_group, u32 ngroups, u64 n,
+                              u64 *d_rng, u32 *d_unit_start2)
+{
+    const u32 total = nb1 * ngroups + 1;
+    hipLaunchKernelGGL(k_make_group_ranges, dim3((total + 255) / 256), dim3(256), 0, st, d_unit_base1, nb1, units_per_group,
+                       ngroups, n, d_rng, d_unit_start2);
+}
+
+void launch_scatter_ranges(hipStream_t st, const void *d_in, void *d_out, u32 nunits, int shift, int bits,
+                           const u64 *d_unit_base, const u64 *d_rng)
+{
+    if (nunits == 0) return;
+    allow_big_lds();
+    hipLaunchKernelGGL(k_scatter_wc, dim3(nunits), dim3(WC_THREADS), wc_lds_bytes(bits), st, (const Tup *)d_in,
+                       (Tup *)d_out, (const u64 *)nullptr, (const u32 *)nullptr, 0u, (u64)0, shift, bits, d_unit_base, d_rng, nunits);
 }
 
 void launch_diff_hist(hipStream_t st, const u64 *d_start, u64 nbins, u64 *d_hist)

@@ -183,8 +183,8 @@ int resolve_plan(u64 nR, u64 nS, const rhj_opts *in, rhj_opts *out)
         // enough tasks to fill 256 CUs even when nothing is partitioned, at most 32 Ki probe tuples each
         const u64 np = nR > nS ? nR : nS;
         u64 ps = (np + 1023) / 1024;
-        ps = (ps + JOIN_TILE - 1) / JOIN_TILE * JOIN_TILE;
-        if (ps < (u64)JOIN_TILE) ps = JOIN_TILE;
+        ps = (ps + BJ_TILE - 1) / BJ_TILE * BJ_TILE;
+        if (ps < (u64)BJ_TILE) ps = BJ_TILE;
         if (ps > 32768) ps = 32768;
         o.probe_split = (int32_t)ps;
     }
@@ -302,8 +302,7 @@ int partition_relation_fused(rhj_ctx *ctx, const void *d_in, u64 n, int b1, int 
 // Partition one relation with `passes` passes into d_out; boundaries into d_ps[2^(b1+b2) + 1].
 int partition_relation(rhj_ctx *ctx, const void *d_in, u64 n, int passes, int b1, int b2, void *d_out, u64 *d_ps)
 {
-    static const bool fused_enabled = !(getenv("RHJ_FUSED") && atoi(getenv("RHJ_FUSED")) == 0);
-    if (passes == 2 && fused_enabled && fused_two_pass_ok(b1, b2) && n > 0 && n < ((u64)1 << 32))
+    if (passes == 2 && fused_two_pass_ok(b1, b2) && n > 0 && n < ((u64)1 << 32))
         return partition_relation_fused(ctx, d_in, n, b1, b2, d_out, d_ps);
     RHJCHK(ensure(ctx, ctx->seg0, 64));
     u64 *seg0 = (u64 *)ctx->seg0.p;
@@ -364,6 +363,9 @@ int join_phase_on(rhj_ctx *ctx, const void *d_Rp, const u64 *d_psR, u64 nR, cons
                   u64 nS, u64 nparts, int radix_bits, u32 probe_split, void *d_out, u64 cap, u64 *out_count)
 {
     if (probe_split == 0) probe_split = 32768;
+    // a task addresses its build range with 32 bits: an unpartitioned side of >= 2^32 tuples needs a radix plan
+    if (nparts == 1 && (nR >> 32 || nS >> 32) && (nR < nS ? nR : nS) >> 32)
+        return fail(ctx, RHJ_E_INVALID, "inputs of 2^32 or more tuples need at least one partition pass");
     const u64 max_tasks64 = nparts + (nR + nS) / probe_split + 1;
     if (max_tasks64 > 0x7fffffffull) return fail(ctx, RHJ_E_INVALID, "too many join tasks");
     const u32 max_tasks = (u32)max_tasks64;

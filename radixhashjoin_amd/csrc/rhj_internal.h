@@ -17,15 +17,7 @@ constexpr int PART_TILE = PART_THREADS * PART_TPT;  // 4096 tuples = 64 KiB LDS 
 constexpr int PART_MAX_BITS = 10;                 // k_scan_units: nbins <= 1024 threads
 constexpr u32 PART_TARGET_UNITS = 2048;           // ~8 units per CU
 
-// ---- bucket join geometry -----------------------------------------------------------------------
-constexpr int JOIN_THREADS = 1024;                // 16 wavefronts, one workgroup per CU
-constexpr int JOIN_CHUNK = 6144;                  // build tuples per LDS hash table (96 KiB keys+rowids)
-constexpr int JOIN_HEADS = 8192;                  // chain heads (32 KiB)
-constexpr int JOIN_EPT = 4;                       // probe tuples per thread per tile
-constexpr int JOIN_TILE = JOIN_THREADS * JOIN_EPT;
-constexpr int JOIN_FILL_NUM = 3, JOIN_FILL_DEN = 4;  // (chained-table kernel) average build partition <= 3/4 chunk
-
-// bucketized-table kernel (production): 512 threads, two workgroups per CU
+// ---- bucket join geometry: bucketized LDS table, 512 threads, two workgroups per CU ------------
 constexpr int BJ_THREADS = 512;
 constexpr int BJ_CHUNK = 4224;                    // build tuples per LDS table: 66 KiB keys+rowids
 constexpr int BJ_BUCKET_BITS = 11;                // 2048 hash buckets (offsets: 8 KiB)
@@ -77,6 +69,5 @@ void launch_make_group_ranges(hipStream_t st, const u64 *d_unit_base1, u32 nb1, 
                               u64 *d_rng, u32 *d_unit_start2);
 void launch_scatter_ranges(hipStream_t st, const void *d_in, void *d_out, u32 nunits, int shift, int bits,
                            const u64 *d_unit_base, const u64 *d_rng);
-size_t join_lds_bytes();
 size_t scan_tmp_bytes(int bits);
 size_t part_lds_bytes(int bits);

@@ -4,10 +4,11 @@
 // k_hist_units           HistogramJob::run            JobScheduler.cpp:149-155     HBM read  (16 B/tuple)
 // k_scan_units           hist reduce + range prefix   structs.cpp:168-173,
 //                                                     JobScheduler.cpp:163-169     latency (KBs)
-// k_scatter_units        PartitionJob scatter + the   JobScheduler.cpp:170-174,
-//                        serial merge-gather          structs.cpp:183-194          HBM read+write (32 B/tuple)
+// k_hist2d_units         the same for both passes of a two-pass plan at once     HBM read  (16 B/tuple, once)
+// k_scatter_wc           PartitionJob scatter + the   JobScheduler.cpp:170-174,
+// (k_scatter_units_pipe) serial merge-gather          structs.cpp:183-194          HBM read+write (32 B/tuple)
 // k_make_tasks           JoinJob scheduling loop      Result.cpp:98-107            latency
-// k_join                 JoinJob::run, join_buckets,  JobScheduler.cpp:186-192,
+// k_join_bkt             JoinJob::run, join_buckets,  JobScheduler.cpp:186-192,
 //                        add_result / addAll          Result.cpp:43-76, 21-35      HBM read+write (16 B/tuple + 16 B/pair)
 //
 // No MFMA anywhere: the path is 64-bit integer hashing and data movement, bounded by HBM.
@@ -363,96 +364,13 @@ k_scan1_final(const u32 *__restrict__ unit_start, int bits, const u32 *__restric
     }
 }
 
-// ------------------------------------------------------------------------------------------------
-// K3: scatter-partition one unit, tile by tile.  PartitionJob::run's scatter (JobScheduler.cpp:170-174)
-// fused with the serial merge-gather of structs.cpp:183-194: tuples go straight to their final
-// slot of R'.  Per 4096-tuple tile: coalesced 16 B loads -> LDS rank per digit -> tile re-ordered
-// by digit in LDS -> each digit's run written as consecutive 16 B stores (write combining:
-// average run = TILE/nbins tuples; consecutive tiles of a unit extend the same nbins streams, so
-// partial 128 B lines complete in the same XCD's L2).
-// ------------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(PART_THREADS)
-k_scatter_units(const Tup *__restrict__ in, Tup *__restrict__ out, const u64 *__restrict__ seg_start,
-                const u32 *__restrict__ unit_start, u32 nseg, u64 L, int shift, int bits,
-                const u64 *__restrict__ unit_base, int ablate)
-{
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    const u32 nbins = 1u << bits, mask = nbins - 1;
-    Tup *tile = reinterpret_cast<Tup *>(smem);                               // PART_TILE * 16 B
-    u64 *gbase = reinterpret_cast<u64 *>(smem + (size_t)PART_TILE * 16);     // nbins * 8
-    u32 *cnt = reinterpret_cast<u32 *>(gbase + nbins);                       // nbins * 4
-    u32 *excl = cnt + nbins;                                                 // nbins * 4
-    u32 *wsum = excl + nbins;                                                // PART_THREADS/64 * 4
-
-    const u32 u = blockIdx.x;
-    if (u >= unit_start[nseg]) return;
-    const u32 s = find_segment(unit_start, nseg, u);
-    const u64 beg = seg_start[s] + (u64)(u - unit_start[s]) * L;
-    const u64 send = seg_start[s + 1];
-    const u64 end = (beg + L < send) ? beg + L : send;
-    const int tid = threadIdx.x;
-    // bins per thread for the in-LDS exclusive scan (consecutive bins)
-    const u32 bpt = (nbins + PART_THREADS - 1) / PART_THREADS;
-
-    for (u32 b = tid; b < nbins; b += PART_THREADS) { gbase[b] = unit_base[(u64)u * nbins + b]; cnt[b] = 0; }
-    __syncthreads();
-
-    for (u64 tb = beg; tb < end; tb += PART_TILE) {
-        const u32 ntile = (end - tb < (u64)PART_TILE) ? (u32)(end - tb) : (u32)PART_TILE;
-        Tup t[PART_TPT];
-        u32 rk[PART_TPT];
-#pragma unroll
-        for (int k = 0; k < PART_TPT; k++) {
-            const u32 i = k * PART_THREADS + tid;
-            if (i < ntile) t[k] = in[tb + i];
-        }
-#pragma unroll
-        for (int k = 0; k < PART_TPT; k++) {
-            const u32 i = k * PART_THREADS + tid;
-            if (i < ntile) rk[k] = (ablate & 4) ? 0u : atomicAdd(&cnt[(u32)(t[k].payload >> shift) & mask], 1u);
-        }
-        __syncthreads();
-        {   // exclusive scan of cnt -> excl
-            u32 loc = 0;
-            const u32 b0 = tid * bpt;
-            for (u32 j = 0; j < bpt; j++) if (b0 + j < nbins) loc += cnt[b0 + j];
-            u32 tot;
-            u32 ex = block_excl_scan<PART_THREADS>(loc, wsum, tot);
-            for (u32 j = 0; j < bpt; j++) if (b0 + j < nbins) { excl[b0 + j] = ex; ex += cnt[b0 + j]; }
-        }
-        __syncthreads();
-#pragma unroll
-        for (int k = 0; k < PART_TPT; k++) {
-            const u32 i = k * PART_THREADS + tid;
-            if (i < ntile) tile[(ablate & 4) ? i : excl[(u32)(t[k].payload >> shift) & mask] + rk[k]] = t[k];
-        }
-        __syncthreads();
-#pragma unroll
-        for (int k = 0; k < PART_TPT; k++) {
-            const u32 i = k * PART_THREADS + tid;
-            if (i < ntile) {
-                const Tup v = tile[i];
-                const u32 dg = (u32)(v.payload >> shift) & mask;
-                const u64 dst = gbase[dg] + (i - excl[dg]);
-                if (ablate & 8) {       // timing-only: data-independent, line-aligned runs of TILE/nbins tuples
-                    const u32 per = PART_TILE >> bits;
-                    const u64 fd = (u64)((i / per) & mask) * (L * unit_start[nseg] >> bits) + ((tb >> bits) + (i % per));  // < L*units <= n when n % L == 0
-                    out[fd] = v;
-                } else
-                if (ablate & 1) { if (dst == 0x7fffffffffffffffull) out[0] = v; }
-                else if (ablate & 2) out[tb + i] = v;
-                else out[dst] = v;
-            }
-        }
-        __syncthreads();
-        for (u32 b = tid; b < nbins; b += PART_THREADS) { gbase[b] += cnt[b]; cnt[b] = 0; }
-        __syncthreads();
-    }
-}
-
 
 // ------------------------------------------------------------------------------------------------
-// K3 (pipelined form).  Same contract as k_scatter_units, restructured for latency:
+// K3 (tile-sort form), used only for 10-bit passes, whose carry lines do not fit LDS beside a tile.
+// PartitionJob::run's scatter (JobScheduler.cpp:170-174) fused with the serial merge-gather of
+// structs.cpp:183-194: tuples go straight to their final slot of R'.  Per 4096-tuple tile: coalesced 16 B
+// loads -> LDS rank per digit -> tile re-ordered by digit in LDS -> each digit's run written as
+// consecutive 16 B stores.  (Its runs start at arbitrary 16 B offsets: 3.4-3.9 TB/s)
 //   * the next tile's 16 B/lane loads are issued into a second register set before the current
 //     tile is processed (plain loads survive __syncthreads on gfx950), so HBM latency overlaps
 //     the LDS phases and the stores of the current tile;
@@ -815,142 +733,10 @@ k_make_tasks(const u64 *__restrict__ startR, const u64 *__restrict__ startS, u64
 }
 
 // ------------------------------------------------------------------------------------------------
-// K4: bucket build + probe + result write.  JoinJob::run + Result::join_buckets (Result.cpp:43-76)
-// with the page appends of add_result/addAll (Result.cpp:21-35, 78-84, 111-121) replaced by a
-// count -> workgroup scan -> one global reservation -> coalesced 16 B pair stores.
-//   build:  LDS chained hash table over a chunk of <= JOIN_CHUNK tuples of the smaller side:
-//           head[h] <- i (LDS atomic exchange), next[i] <- previous head   (Result.cpp:54-58)
-//   probe:  per probe tuple walk the chain with full 64-bit compares       (Result.cpp:61-73)
-// The hash is Fibonacci hashing of the payload bits above the radix bits (those below are equal
-// inside a partition); the result set does not depend on it (full-key equality test).
-// ------------------------------------------------------------------------------------------------
-__device__ __forceinline__ u32 hash_slot(u64 v, int radix_bits)
-{
-    return (u32)(((v >> radix_bits) * 0x9E3779B97F4A7C15ULL) >> (64 - 13));   // JOIN_HEADS = 2^13
-}
-static_assert(JOIN_HEADS == (1 << 13), "hash_slot assumes 8192 heads");
-static_assert(JOIN_CHUNK < 65535, "next[] is 16-bit");
-
-__global__ void __launch_bounds__(JOIN_THREADS)
-k_join(const Tup *__restrict__ R, const u64 *__restrict__ startR, const Tup *__restrict__ S,
-       const u64 *__restrict__ startS, const JoinTask *__restrict__ tasks, const u32 *__restrict__ ntasks,
-       int radix_bits, Pair *__restrict__ out, u64 out_capacity, u64 *__restrict__ out_count)
-{
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    u64 *keys = reinterpret_cast<u64 *>(smem);                       // JOIN_CHUNK * 8
-    u64 *rids = keys + JOIN_CHUNK;                                   // JOIN_CHUNK * 8
-    u32 *head = reinterpret_cast<u32 *>(rids + JOIN_CHUNK);          // JOIN_HEADS * 4   (index+1, 0 = empty)
-    unsigned short *next = reinterpret_cast<unsigned short *>(head + JOIN_HEADS);  // JOIN_CHUNK * 2
-    u32 (*wsum)[JOIN_THREADS / 64] = reinterpret_cast<u32 (*)[JOIN_THREADS / 64]>(next + JOIN_CHUNK);  // EPT*16*4
-    u64 *gres_p = reinterpret_cast<u64 *>(&wsum[JOIN_EPT][0]);
-
-    if (blockIdx.x >= *ntasks) return;
-    const JoinTask task = tasks[blockIdx.x];
-    const u64 r0 = startR[task.part], nr = startR[task.part + 1] - r0;
-    const u64 s0 = startS[task.part], ns = startS[task.part + 1] - s0;
-    const bool build_is_S = (nr >= ns);                              // JobScheduler.cpp:187
-    const Tup *__restrict__ B = build_is_S ? S + s0 : R + r0;
-    const u64 nb = build_is_S ? ns : nr;
-    const Tup *__restrict__ P = (build_is_S ? R : S) + task.pbeg;
-    const u32 np = task.plen;
-    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-
-    for (u64 cb = 0; cb < nb; cb += JOIN_CHUNK) {
-        const u32 nc = (nb - cb < (u64)JOIN_CHUNK) ? (u32)(nb - cb) : (u32)JOIN_CHUNK;
-        for (u32 h = tid; h < JOIN_HEADS; h += JOIN_THREADS) head[h] = 0;
-        __syncthreads();
-        for (u32 i = tid; i < nc; i += JOIN_THREADS) {
-            const Tup t = B[cb + i];
-            keys[i] = t.payload;
-            rids[i] = t.key;
-            const u32 old = atomicExch(&head[hash_slot(t.payload, radix_bits)], i + 1);
-            next[i] = (unsigned short)old;
-        }
-        __syncthreads();
-
-        for (u32 tb = 0; tb < np; tb += JOIN_TILE) {
-            Tup p[JOIN_EPT];
-            u32 cnt[JOIN_EPT], first[JOIN_EPT];
-#pragma unroll
-            for (int k = 0; k < JOIN_EPT; k++) {
-                const u32 i = tb + k * JOIN_THREADS + tid;
-                cnt[k] = 0; first[k] = 0;
-                if (i < np) p[k] = P[i];
-            }
-#pragma unroll
-            for (int k = 0; k < JOIN_EPT; k++) {
-                const u32 i = tb + k * JOIN_THREADS + tid;
-                if (i < np) {
-                    u32 j = head[hash_slot(p[k].payload, radix_bits)];
-                    while (j) {
-                        if (keys[j - 1] == p[k].payload) { if (!cnt[k]) first[k] = j; cnt[k]++; }
-                        j = next[j - 1];
-                    }
-                }
-            }
-            // JOIN_EPT simultaneous workgroup scans (slot-major output order => consecutive lanes write
-            // consecutive pairs when each probe tuple has one match)
-            u32 inc[JOIN_EPT];
-#pragma unroll
-            for (int k = 0; k < JOIN_EPT; k++) inc[k] = cnt[k];
-#pragma unroll
-            for (int off = 1; off < 64; off <<= 1) {
-#pragma unroll
-                for (int k = 0; k < JOIN_EPT; k++) {
-                    const u32 t = __shfl_up(inc[k], off, 64);
-                    if (lane >= off) inc[k] += t;
-                }
-            }
-            if (lane == 63) {
-#pragma unroll
-                for (int k = 0; k < JOIN_EPT; k++) wsum[k][w] = inc[k];
-            }
-            __syncthreads();
-            u64 slot_base[JOIN_EPT];
-            u64 tile_total = 0;
-#pragma unroll
-            for (int k = 0; k < JOIN_EPT; k++) {
-                u32 pre = 0, tot = 0;
-#pragma unroll
-                for (int i = 0; i < JOIN_THREADS / 64; i++) { const u32 x = wsum[k][i]; if (i < w) pre += x; tot += x; }
-                slot_base[k] = tile_total + pre + inc[k] - cnt[k];
-                tile_total += tot;
-            }
-            if (tid == 0 && tile_total) *gres_p = atomicAdd(out_count, tile_total);
-            __syncthreads();
-            if (tile_total && out != nullptr) {
-                const u64 g = *gres_p;
-#pragma unroll
-                for (int k = 0; k < JOIN_EPT; k++) {
-                    if (cnt[k] == 0) continue;
-                    u64 o = g + slot_base[k];
-                    u32 j = first[k];
-                    u32 left = cnt[k];
-                    while (left) {                       // first[k] is the first match: at most cnt[k] hops matter
-                        if (keys[j - 1] == p[k].payload) {
-                            if (o < out_capacity) {
-                                Pair pr;
-                                if (build_is_S) { pr.r = p[k].key; pr.s = rids[j - 1]; }   // orderFlag, Result.cpp:64-68
-                                else            { pr.r = rids[j - 1]; pr.s = p[k].key; }
-                                out[o] = pr;
-                            }
-                            o++; left--;
-                        }
-                        j = next[j - 1];
-                    }
-                }
-            }
-            __syncthreads();     // gres_p / wsum reuse
-        }
-        __syncthreads();         // table reuse by the next build chunk
-    }
-}
-
-
-// ------------------------------------------------------------------------------------------------
-// K4 (bucketized LDS table) -- the production bucket-join kernel.
-// JoinJob::run + Result::join_buckets (Result.cpp:43-76) + add_result/addAll.  Differences from the
-// chained-table form above, all forced by latency on a 256-CU part:
+// K4 (bucketized LDS table): bucket build + probe + result write.
+// JoinJob::run + Result::join_buckets (Result.cpp:43-76) + the page appends of add_result/addAll
+// (Result.cpp:21-35, 78-84, 111-121).  The reference builds bucket[next_prime(n)] + chain[n]; the result set
+// does not depend on the hash (full 64-bit equality), so the table here is shaped by latency on a 256-CU part:
 //   * 512 threads and <= 80 KiB LDS: two workgroups per CU overlap each other's global-load and
 //     atomic round trips;
 //   * the table is the build chunk itself re-ordered by hash bucket (LDS counting sort: per-bucket
@@ -986,7 +772,7 @@ template <int THREADS, int CHUNK, int BBITS, int EPT>
 __global__ void __launch_bounds__(THREADS, 4)
 k_join_bkt(const Tup *__restrict__ R, const Tup *__restrict__ S, const JoinTask *__restrict__ tasks,
            const u32 *__restrict__ ntasks, int radix_bits, Pair *__restrict__ out, u64 out_capacity,
-           u64 *__restrict__ out_count, int ablate)
+           u64 *__restrict__ out_count)
 {
     constexpr int NB = 1 << BBITS;
     constexpr int NW = THREADS / 64;
@@ -1060,7 +846,6 @@ k_join_bkt(const Tup *__restrict__ R, const Tup *__restrict__ S, const JoinTask 
         __syncthreads();
 
         // ---- probe ------------------------------------------------------------------------------
-        if (ablate & 4) continue;
         for (u32 tb = 0; tb < np; tb += TILE) {
             if (tb != 0 || cb != 0) {
 #pragma unroll
@@ -1120,10 +905,10 @@ k_join_bkt(const Tup *__restrict__ R, const Tup *__restrict__ S, const JoinTask 
             const u32 mine = wtot[lane];
             const u32 inc64 = wave_incl_scan(mine, lane);
             const u32 tile_total = __shfl(inc64, 63, 64);
-            if (tid == 0 && tile_total) *gres = (ablate & 2) ? (u64)blockIdx.x * 4096 % 900000000ull : atomicAdd(out_count, (u64)tile_total);
+            if (tid == 0 && tile_total) *gres = atomicAdd(out_count, (u64)tile_total);
             __syncthreads();
-            if (tile_total && out != nullptr && !(ablate & 1)) {
-                const u64 g = (ablate & 8) ? (*gres & ~7ull) : *gres;
+            if (tile_total && out != nullptr) {
+                const u64 g = *gres;
 #pragma unroll
                 for (int k = 0; k < EPT; k++) {
                     const u32 sbase = __shfl(inc64 - mine, k * NW + w, 64);   // exclusive prefix of (slot k, wave w)
@@ -1256,7 +1041,7 @@ size_t scan_tmp_bytes(int bits) { return (size_t)SCAN_SLICES * ((size_t)8 << bit
 size_t part_lds_bytes(int bits)
 {
     const size_t nbins = (size_t)1 << bits;
-    return (size_t)PART_TILE * 16 + nbins * (8 + 8 + 4 + 4) + (PART_THREADS / 64) * 4;
+    return (size_t)PART_TILE * 16 + nbins * (8 + 8 + 4 + 4);
 }
 
 static size_t wc_lds_bytes(int bits)
@@ -1272,19 +1057,11 @@ static size_t bj_lds_bytes(int threads, int chunk, int bbits)
     return (size_t)chunk * 16 + ((size_t)(1 << bbits) + 4) * 4 + 64 * 4 + (size_t)(threads / 64) * 4 + 16;
 }
 
-size_t join_lds_bytes()
-{
-    return (size_t)JOIN_CHUNK * 16 + (size_t)JOIN_HEADS * 4 + (size_t)JOIN_CHUNK * 2 +
-           (size_t)JOIN_EPT * (JOIN_THREADS / 64) * 4 + 16;
-}
-
 static void allow_big_lds()
 {
     static bool done = false;
     if (done) return;
     done = true;
-    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_scatter_units),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)part_lds_bytes(PART_MAX_BITS));
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_scatter_units_pipe),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)part_lds_bytes(PART_MAX_BITS));
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_scatter_wc),
@@ -1295,8 +1072,6 @@ static void allow_big_lds()
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_join_bkt<BJ2_THREADS, BJ2_CHUNK, BJ2_BUCKET_BITS, BJ2_EPT>),
                               hipFuncAttributeMaxDynamicSharedMemorySize,
                               (int)bj_lds_bytes(BJ2_THREADS, BJ2_CHUNK, BJ2_BUCKET_BITS));
-    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_join),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)join_lds_bytes());
 }
 
 void launch_init_single_segment(hipStream_t st, u64 n, u64 L, u64 *d_seg_start, u32 *d_unit_start)
@@ -1338,22 +1113,16 @@ void launch_scatter_units(hipStream_t st, const void *d_in, void *d_out, const P
 {
     if (g.max_units == 0) return;
     allow_big_lds();
-    static const int variant = getenv("RHJ_SCATTER") ? atoi(getenv("RHJ_SCATTER")) : 2;
-    if (variant == 2 && g.bits <= WC_MAX_BITS) {
+    if (g.bits <= WC_MAX_BITS) {
         hipLaunchKernelGGL(k_scatter_wc, dim3(g.max_units), dim3(WC_THREADS), wc_lds_bytes(g.bits), st,
                            (const Tup *)d_in, (Tup *)d_out, d_seg_start, d_unit_start, g.nseg, g.L, g.shift, g.bits,
                            d_unit_base, (const u64 *)nullptr, 0u);
         return;
     }
-    if (variant >= 1) {
-        hipLaunchKernelGGL(k_scatter_units_pipe, dim3(g.max_units), dim3(PART_THREADS), part_lds_bytes(g.bits), st,
-                           (const Tup *)d_in, (Tup *)d_out, d_seg_start, d_unit_start, g.nseg, g.L, g.shift, g.bits,
-                           d_unit_base);
-        return;
-    }
-    hipLaunchKernelGGL(k_scatter_units, dim3(g.max_units), dim3(PART_THREADS), part_lds_bytes(g.bits), st,
+    // 10-bit pass: carry lines (2^10 x 128 B) do not fit LDS beside a tile -> tile-sort form
+    hipLaunchKernelGGL(k_scatter_units_pipe, dim3(g.max_units), dim3(PART_THREADS), part_lds_bytes(g.bits), st,
                        (const Tup *)d_in, (Tup *)d_out, d_seg_start, d_unit_start, g.nseg, g.L, g.shift, g.bits,
-                       d_unit_base, getenv("RHJ_ABLATE") ? atoi(getenv("RHJ_ABLATE")) : 0);
+                       d_unit_base);
 }
 
 bool fused_two_pass_ok(int b1, int b2) { return b1 >= 1 && b2 >= 1 && b1 <= WC_MAX_BITS && b2 <= WC_MAX_BITS && b1 + b2 <= 16; }
@@ -1413,23 +1182,15 @@ void launch_join(hipStream_t st, const void *d_R, const u64 *d_startR, const voi
 {
     if (grid == 0) return;
     allow_big_lds();
-    static const int variant = getenv("RHJ_JOIN") ? atoi(getenv("RHJ_JOIN")) : 1;
-    static const int jabl = getenv("RHJ_JABL") ? atoi(getenv("RHJ_JABL")) : 0;      // development ablations
-    if (variant == 1 && !big_tables) {
+    if (!big_tables) {
         hipLaunchKernelGGL((k_join_bkt<BJ_THREADS, BJ_CHUNK, BJ_BUCKET_BITS, BJ_EPT>), dim3(grid), dim3(BJ_THREADS),
                            bj_lds_bytes(BJ_THREADS, BJ_CHUNK, BJ_BUCKET_BITS), st, (const Tup *)d_R, (const Tup *)d_S,
-                           d_tasks, d_ntasks, radix_bits, (Pair *)d_out, out_capacity, d_out_count, jabl);
+                           d_tasks, d_ntasks, radix_bits, (Pair *)d_out, out_capacity, d_out_count);
         return;
     }
-    if (variant == 1) {
-        hipLaunchKernelGGL((k_join_bkt<BJ2_THREADS, BJ2_CHUNK, BJ2_BUCKET_BITS, BJ2_EPT>), dim3(grid), dim3(BJ2_THREADS),
-                           bj_lds_bytes(BJ2_THREADS, BJ2_CHUNK, BJ2_BUCKET_BITS), st, (const Tup *)d_R, (const Tup *)d_S,
-                           d_tasks, d_ntasks, radix_bits, (Pair *)d_out, out_capacity, d_out_count, jabl);
-        return;
-    }
-    hipLaunchKernelGGL(k_join, dim3(grid), dim3(JOIN_THREADS), join_lds_bytes(), st, (const Tup *)d_R, d_startR,
-                       (const Tup *)d_S, d_startS, d_tasks, d_ntasks, radix_bits, (Pair *)d_out, out_capacity,
-                       d_out_count);
+    hipLaunchKernelGGL((k_join_bkt<BJ2_THREADS, BJ2_CHUNK, BJ2_BUCKET_BITS, BJ2_EPT>), dim3(grid), dim3(BJ2_THREADS),
+                       bj_lds_bytes(BJ2_THREADS, BJ2_CHUNK, BJ2_BUCKET_BITS), st, (const Tup *)d_R, (const Tup *)d_S,
+                       d_tasks, d_ntasks, radix_bits, (Pair *)d_out, out_capacity, d_out_count);
 }
 
 static unsigned stream_grid(u64 n)

@@ -299,3 +299,35 @@ def test_large_device_resident(engine, n, plan, kind):
     assert got == exp_n == n
     assert engine.pairs_checksum(dO, n) == exp_c
     engine.release_workspace()
+
+
+def test_concurrent_contexts(oracle):
+    """8 caller threads, each with its own rhj_ctx, joining at the same time on one GPU -- the reference's
+    threading contract at the boundary (MainScheduler.cpp:6-14: 8 query threads, private JobSchedulers)."""
+    import threading
+    from radixhashjoin_amd import Engine
+    cases = []
+    for i in range(8):
+        nR, nS, D = 20_000 + 7_000 * i, 90_000 - 5_000 * i, 5_000 + 3_000 * i
+        R, S = oracle.gen_R(nR, D), oracle.gen_S_chain(nS, D)
+        cases.append((R, S, oracle.join_count_checksum(R, S)))
+    results, errors = [None] * 8, []
+
+    def work(i):
+        try:
+            e = Engine(0)
+            for _ in range(5):
+                p = e.join(cases[i][0], cases[i][1])
+                results[i] = (len(p), oracle.pairs_checksum(p))
+                assert results[i] == cases[i][2]
+            e.close()
+        except Exception as ex:          # noqa: BLE001
+            errors.append((i, repr(ex)))
+
+    threads = [threading.Thread(target=work, args=(i,)) for i in range(8)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors, errors
+    assert [r for r in results] == [c[2] for c in cases]

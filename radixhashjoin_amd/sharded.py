@@ -10,7 +10,8 @@ ONE exchange step, an all-to-all of tuples by OWNER RADIX BITS:
      (rhj_partition_at): tuples for rank d become contiguous, d = 0..world-1;
   2. a tiny all-to-all of the per-destination counts, then ONE all_to_all_single of the tuples
      (RCCL: world-1 direct peer sends over xGMI, all links busy at once, no multi-hop); the
-     exchange of R is in flight while S is being split;
+     exchange of R is in flight while S is being split, the exchange of S while the received R is
+     radix-partitioned locally;
   3. every rank now holds ALL tuples of its owner class of both relations and runs the normal
      single-GPU join (rhj_join_dev: 1-2 radix passes on the low bits + LDS bucket join) locally.
      Owner bits lie above every bit the local plan can use (2 * 10), so the local plan is untouched.
@@ -38,6 +39,7 @@ class ShardedJoin:
         self.owner_bits = self.world.bit_length() - 1
         self.owner_shift = owner_shift
         self.local_opts = local_opts
+        self.staged_local_join = True        # False: one rhj_join_dev call after both exchanges (no S-transfer overlap)
         self.stats = {}
 
     # -- step 1: owner split of one shard (compute) ------------------------------------------------
@@ -82,24 +84,64 @@ class ShardedJoin:
 
     def join(self, R, nR, S, nS, out=None):
         """Local shards in, local share of the result out: (count, [count,2] tensor of {rowR,rowS}).
-        Schedule: split R | exchange R overlapped with split S | exchange S | local join."""
+
+        Schedule (communication on the RCCL stream, kernels on the engine's stream):
+            split R | exchange R  ||  split S | exchange S  ||  partition received R | partition received S | bucket join
+        i.e. the R transfer overlaps the owner split of S, and the S transfer overlaps the local radix
+        partitioning of R (stage entry points rhj_partition / rhj_bucket_join of the C-ABI)."""
         if self.world == 1:
-            Rx, mR, Sx, mS = R, nR, S, nS
-        else:
-            stagedR, cR = self.split(R, nR)
-            hR = self.start_exchange(stagedR, nR, cR)          # R tuples on the wire ...
-            stagedS, cS = self.split(S, nS)                    # ... while S is being split
-            hS = self.start_exchange(stagedS, nS, cS)
-            Rx, mR = self.finish_exchange(hR)
-            Sx, mS = self.finish_exchange(hS)
+            return self._local_join_whole(R, nR, S, nS, out)
+        stagedR, cR = self.split(R, nR)
+        hR = self.start_exchange(stagedR, nR, cR)              # R tuples on the wire ...
+        stagedS, cS = self.split(S, nS)                        # ... while S is being split
+        hS = self.start_exchange(stagedS, nS, cS)
+        mR, mS = hR[1], hS[1]                                  # received sizes are known from the count exchange
         self.stats = {"recv_R": mR, "recv_S": mS}
+        if not self.staged_local_join or not hasattr(self.engine, "partition"):
+            Rx, _ = self.finish_exchange(hR)
+            Sx, _ = self.finish_exchange(hS)
+            return self._local_join_whole(Rx, mR, Sx, mS, out)
+        plan = self._plan(mR, mS)
+        dev = R.device
+        Rx, _ = self.finish_exchange(hR)
+        if plan.passes == 0 or mR == 0 or mS == 0:
+            Sx, _ = self.finish_exchange(hS)
+            return self._local_join_whole(Rx, mR, Sx, mS, out)
+        b1, b2 = plan.bits1, (plan.bits2 if plan.passes == 2 else 0)
+        nparts = 1 << (b1 + b2)
+        partR = torch.empty((max(mR, 1), 2), dtype=torch.int64, device=dev)
+        psR = torch.empty(nparts + 1, dtype=torch.int64, device=dev)
+        self._fence_torch(dev)                                 # R has landed; S is still in flight
+        self.engine.partition(Rx, mR, b1, b2, partR, psR)      # local radix passes over R overlap the S transfer
+        Sx, _ = self.finish_exchange(hS)
+        partS = torch.empty((max(mS, 1), 2), dtype=torch.int64, device=dev)
+        psS = torch.empty(nparts + 1, dtype=torch.int64, device=dev)
+        self._fence_torch(dev)
+        self.engine.partition(Sx, mS, b1, b2, partS, psS)
         cap = out.shape[0] if out is not None else max(mR, mS) + 1024
         if out is None:
-            out = torch.empty((cap, 2), dtype=torch.int64, device=R.device)
-        self._fence_torch(R.device)               # the received tuples have landed (collective complete)
+            out = torch.empty((cap, 2), dtype=torch.int64, device=dev)
+        self._fence_torch(dev)
+        cnt = self.engine.bucket_join(partR, psR, partS, psS, nparts, b1 + b2, out, cap,
+                                      probe_split=plan.probe_split, allow_overflow=True)
+        if cnt > cap:
+            out = torch.empty((cnt, 2), dtype=torch.int64, device=dev)
+            self._fence_torch(dev)
+            cnt = self.engine.bucket_join(partR, psR, partS, psS, nparts, b1 + b2, out, cnt, probe_split=plan.probe_split)
+        return cnt, out
+
+    def _plan(self, mR, mS):
+        from .binding import plan as resolve
+        return resolve(mR, mS, self.local_opts)
+
+    def _local_join_whole(self, Rx, mR, Sx, mS, out):
+        cap = out.shape[0] if out is not None else max(mR, mS) + 1024
+        if out is None:
+            out = torch.empty((cap, 2), dtype=torch.int64, device=Rx.device)
+        self._fence_torch(Rx.device)              # the received tuples have landed (collective complete)
         cnt = self.engine.join_dev(Rx, mR, Sx, mS, out, cap, opts=self.local_opts, allow_overflow=True)
         if cnt > cap:                              # more pairs than guessed: exact size is known now
-            out = torch.empty((cnt, 2), dtype=torch.int64, device=R.device)
+            out = torch.empty((cnt, 2), dtype=torch.int64, device=Rx.device)
             cnt = self.engine.join_dev(Rx, mR, Sx, mS, out, cnt, opts=self.local_opts)
         return cnt, out
 

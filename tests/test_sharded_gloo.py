@@ -33,6 +33,27 @@ class OracleEngine:
         d_out.numpy()[:n] = a[order]
         d_part_start.numpy()[:] = np.concatenate([[0], np.cumsum(np.bincount(dig, minlength=1 << bits))])
 
+    def partition(self, d_in, n, bits1, bits2, d_out, d_part_start):
+        # layout documented in include/rhj.h: pass-1 digit major, pass-2 digit minor
+        a = self._np(d_in, n)
+        p = (a[:, 1].astype(np.uint64) & np.uint64((1 << (bits1 + bits2)) - 1)).astype(np.int64)
+        oid = ((p & ((1 << bits1) - 1)) << bits2) | (p >> bits1)
+        order = np.argsort(oid, kind="stable")
+        d_out.numpy()[:n] = a[order]
+        d_part_start.numpy()[:] = np.concatenate([[0], np.cumsum(np.bincount(oid, minlength=1 << (bits1 + bits2)))])
+
+    def bucket_join(self, d_Rp, d_startR, d_Sp, d_startS, nparts, radix_bits, d_out=None, capacity=0, probe_split=0,
+                    allow_overflow=False):
+        nR, nS = int(d_startR.numpy()[nparts]), int(d_startS.numpy()[nparts])
+        # partitions must be aligned for a bucket join: same digit at the same index on both sides
+        for t, st in ((d_Rp, d_startR), (d_Sp, d_startS)):
+            a, b = self._np(t, nR if t is d_Rp else nS), st.numpy()
+            low = (a[:, 1].astype(np.uint64) & np.uint64((1 << radix_bits) - 1)).astype(np.int64)
+            for k in (0, nparts // 2, nparts - 1):
+                seg = low[b[k]:b[k + 1]]
+                assert len(np.unique(seg)) <= 1
+        return self.join_dev(d_Rp, nR, d_Sp, nS, d_out, capacity)
+
     def join_dev(self, d_R, nR, d_S, nS, d_out=None, capacity=0, opts=None, allow_overflow=False):
         from oracle.pyoracle import TUPLE
         R = np.ascontiguousarray(self._np(d_R, nR)).view(np.uint64).reshape(-1, 2)
@@ -47,7 +68,7 @@ class OracleEngine:
         return len(p)
 
 
-def worker(rank, world, port, n_per_rank, dup, q):
+def worker(rank, world, port, n_per_rank, dup, staged, q):
     sys.path.insert(0, ROOT)
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
@@ -66,6 +87,7 @@ def worker(rank, world, port, n_per_rank, dup, q):
         return torch.from_numpy(a.view(np.int64))
 
     sj = ShardedJoin(OracleEngine(), dist.group.WORLD)
+    sj.staged_local_join = staged
     cnt, out = sj.join(shard(Rg), n_per_rank, shard(Sg), n_per_rank)
     pairs = out.numpy()[:cnt].view(np.uint64)
     # every pair this rank produced belongs to its owner class
@@ -92,12 +114,13 @@ def free_port():
     return p
 
 
-@pytest.mark.parametrize("world,n_per_rank,dup", [(2, 20_000, 1), (2, 5_000, 4), (4, 6_000, 2)])
-def test_sharded_join_equals_global_join(world, n_per_rank, dup):
+@pytest.mark.parametrize("world,n_per_rank,dup,staged", [(2, 20_000, 1, True), (2, 5_000, 4, False), (4, 6_000, 2, True),
+                                                         (2, 1_000, 1, True)])
+def test_sharded_join_equals_global_join(world, n_per_rank, dup, staged):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = free_port()
-    procs = [ctx.Process(target=worker, args=(r, world, port, n_per_rank, dup, q)) for r in range(world)]
+    procs = [ctx.Process(target=worker, args=(r, world, port, n_per_rank, dup, staged, q)) for r in range(world)]
     for p in procs:
         p.start()
     got, exp, same, stats = q.get(timeout=180)

@@ -119,6 +119,7 @@ def main():
     else:
         from radixhashjoin_amd.sharded import ShardedJoin
         sj = ShardedJoin(eng, dist.group.WORLD, local_opts=opts)
+        sj.collect_timings = True
 
         def step():
             return sj.join(R, n, S, n)
@@ -131,16 +132,22 @@ def main():
     for _ in range(args.warmup):
         step()
     eng.set_profiling(True)
+    if world > 1:
+        sj.kernel_ms = {}
     kt = {"hist": [0.0, 0], "scan": [0.0, 0], "scatter": [0.0, 0], "tasks": [0.0, 0], "join": [0.0, 0], "aux": [0.0, 0]}
     barrier()
     t0 = time.perf_counter()
     cnt, res = 0, None
     for _ in range(args.steps):
         cnt, res = step()
-        t = eng.timings()                              # HIP events recorded around every launch of this step
+        if world == 1:
+            t = eng.timings()                          # HIP events recorded around every launch of this step
+            for k in kt:
+                kt[k][0] += t[k]["ms"]
+                kt[k][1] += t[k]["launches"]
+    if world > 1:                                      # summed by the sharded driver over the engine calls of every step
         for k in kt:
-            kt[k][0] += t[k]["ms"]
-            kt[k][1] += t[k]["launches"]
+            kt[k] = list(sj.kernel_ms.get(k, [0.0, 0]))
     barrier()
     dt = time.perf_counter() - t0
     eng.set_profiling(False)

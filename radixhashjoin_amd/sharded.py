@@ -40,6 +40,8 @@ class ShardedJoin:
         self.owner_shift = owner_shift
         self.local_opts = local_opts
         self.staged_local_join = True        # False: one rhj_join_dev call after both exchanges (no S-transfer overlap)
+        self.collect_timings = False         # True: sum the engine's per-kernel HIP-event timings over the calls of a join
+        self.kernel_ms = {}
         self.stats = {}
 
     # -- step 1: owner split of one shard (compute) ------------------------------------------------
@@ -113,11 +115,13 @@ class ShardedJoin:
         psR = torch.empty(nparts + 1, dtype=torch.int64, device=dev)
         self._fence_torch(dev)                                 # R has landed; S is still in flight
         self.engine.partition(Rx, mR, b1, b2, partR, psR)      # local radix passes over R overlap the S transfer
+        self._collect()
         Sx, _ = self.finish_exchange(hS)
         partS = torch.empty((max(mS, 1), 2), dtype=torch.int64, device=dev)
         psS = torch.empty(nparts + 1, dtype=torch.int64, device=dev)
         self._fence_torch(dev)
         self.engine.partition(Sx, mS, b1, b2, partS, psS)
+        self._collect()
         cap = out.shape[0] if out is not None else max(mR, mS) + 1024
         if out is None:
             out = torch.empty((cap, 2), dtype=torch.int64, device=dev)
@@ -128,6 +132,7 @@ class ShardedJoin:
             out = torch.empty((cnt, 2), dtype=torch.int64, device=dev)
             self._fence_torch(dev)
             cnt = self.engine.bucket_join(partR, psR, partS, psS, nparts, b1 + b2, out, cnt, probe_split=plan.probe_split)
+        self._collect()
         return cnt, out
 
     def _plan(self, mR, mS):
@@ -143,6 +148,7 @@ class ShardedJoin:
         if cnt > cap:                              # more pairs than guessed: exact size is known now
             out = torch.empty((cnt, 2), dtype=torch.int64, device=Rx.device)
             cnt = self.engine.join_dev(Rx, mR, Sx, mS, out, cnt, opts=self.local_opts)
+        self._collect()
         return cnt, out
 
     # The engine launches on its own HIP stream unless it was given torch's (rhj_set_stream); these two
@@ -155,6 +161,17 @@ class ShardedJoin:
         sync = getattr(self.engine, "sync", None)
         if sync is not None:
             sync()
+        self._collect()
+
+    def _collect(self):
+        if not self.collect_timings or not hasattr(self.engine, "timings"):
+            return
+        t = self.engine.timings()            # of the engine call that just finished (synchronises its stream)
+        for k, v in t.items():
+            if isinstance(v, dict):
+                acc = self.kernel_ms.setdefault(k, [0.0, 0])
+                acc[0] += v["ms"]
+                acc[1] += v["launches"]
 
     def _a2a(self, out, inp, out_splits, in_splits, async_op=False):
         """all_to_all_single; with a backend that cannot move device memory (gloo rehearsal of the

@@ -16,6 +16,18 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "slow: long-running CPU test, skipped unless RHJ_SLOW=1")
 
 
+def pytest_sessionstart(session):
+    """Built artefacts are git-ignored: if this checkout has not been built yet, build it (hipcc cross-compiles
+    gfx950 without a GPU; the oracle needs only gcc)."""
+    need = [os.path.join(ROOT, "radixhashjoin_amd", "librhj_hip.so"), os.path.join(ROOT, "oracle", "liborc.so"),
+            os.path.join(ROOT, "radixhashjoin_amd", "host", "join_gpu"),
+            os.path.join(ROOT, "radixhashjoin_amd", "host", "host_driver"),
+            os.path.join(ROOT, "radixhashjoin_amd", "host", "query_unit")]
+    if not all(os.path.exists(p) for p in need):
+        import __graft_entry__
+        __graft_entry__.build()
+
+
 def pytest_collection_modifyitems(config, items):
     if os.environ.get("RHJ_SLOW") == "1":
         return

@@ -497,18 +497,21 @@ k_scatter_units_pipe(const Tup *__restrict__ in, Tup *__restrict__ out, const u6
 // One workgroup of 1024 threads per CU (tile 64 KiB + carry lines nbins*128 B), next tile's 16 B/lane
 // loads prefetched into a second register set, 4 workgroup barriers per tile.
 // ------------------------------------------------------------------------------------------------
-constexpr int WC_THREADS = 1024, WC_TPT = 4, WC_TILE = WC_THREADS * WC_TPT;
+constexpr int WC_THREADS = 1024, WC_TPT = 4;                                // geometry for 9-bit passes (tile = THREADS * WC_TPT)
+constexpr int WC_THREADS_SMALL = 512;                                       // <= 8 bits: two workgroups per CU
 constexpr int WC_MAX_BITS = 9;
 
-__global__ void __launch_bounds__(WC_THREADS)
+template <int THREADS>
+__global__ void __launch_bounds__(THREADS)
 k_scatter_wc(const Tup *__restrict__ in, Tup *__restrict__ out, const u64 *__restrict__ seg_start,
              const u32 *__restrict__ unit_start, u32 nseg, u64 L, int shift, int bits,
              const u64 *__restrict__ unit_base, const u64 *__restrict__ unit_rng, u32 n_rng_units)
 {
+    constexpr int TILE = THREADS * WC_TPT;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const u32 nbins = 1u << bits, mask = nbins - 1;
-    Tup *tile = reinterpret_cast<Tup *>(smem);                               // WC_TILE * 16
-    Tup *cb = tile + WC_TILE;                                                // nbins * 8 * 16
+    Tup *tile = reinterpret_cast<Tup *>(smem);                               // TILE * 16
+    Tup *cb = tile + TILE;                                                // nbins * 8 * 16
     u64 *gnext = reinterpret_cast<u64 *>(cb + (size_t)nbins * 8);            // next global index per digit
     u64 *A = gnext + nbins;                                                  // staging slot i -> global index A[d] + i
     u64 *LB = A + nbins;                                                     // carry-line flush: (line base | first slot), ~0 = none
@@ -516,7 +519,7 @@ k_scatter_wc(const Tup *__restrict__ in, Tup *__restrict__ out, const u64 *__res
     u32 *P = cnt + nbins;                                                    // sexcl | heads << 16 | (g0 & 7) << 20
     u32 *LO = P + nbins;                                                     // first valid slot of the carried line
     u32 *mtot = LO + nbins;                                                  // staged tuples of this tile
-    u32 *wsc = mtot + 4;                                                     // WC_THREADS/64 wave totals
+    u32 *wsc = mtot + 4;                                                     // THREADS/64 wave totals
 
     const u32 u = blockIdx.x;
     u64 beg, end;
@@ -533,7 +536,7 @@ k_scatter_wc(const Tup *__restrict__ in, Tup *__restrict__ out, const u64 *__res
     }
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
 
-    for (u32 b = tid; b < nbins; b += WC_THREADS) {
+    for (u32 b = tid; b < nbins; b += THREADS) {
         const u64 g = unit_base[(u64)u * nbins + b];
         gnext[b] = g;
         LO[b] = (u32)g & 7u;
@@ -542,24 +545,24 @@ k_scatter_wc(const Tup *__restrict__ in, Tup *__restrict__ out, const u64 *__res
     __syncthreads();
 
     auto load_tile = [&](Tup (&t)[WC_TPT], u64 tb) {
-        const u32 ntile = (end - tb < (u64)WC_TILE) ? (u32)(end - tb) : (u32)WC_TILE;
+        const u32 ntile = (end - tb < (u64)TILE) ? (u32)(end - tb) : (u32)TILE;
         const Tup *__restrict__ tp = in + tb;
 #pragma unroll
         for (int k = 0; k < WC_TPT; k++) {
-            const u32 i = k * WC_THREADS + tid;
+            const u32 i = k * THREADS + tid;
             if (i < ntile) t[k] = tp[i];
         }
     };
     auto process = [&](Tup (&t)[WC_TPT], u64 tb) {
-        const u32 ntile = (end - tb < (u64)WC_TILE) ? (u32)(end - tb) : (u32)WC_TILE;
+        const u32 ntile = (end - tb < (u64)TILE) ? (u32)(end - tb) : (u32)TILE;
         u32 rk[WC_TPT];
 #pragma unroll
         for (int k = 0; k < WC_TPT; k++) {
-            const u32 i = k * WC_THREADS + tid;
+            const u32 i = k * THREADS + tid;
             if (i < ntile) rk[k] = atomicAdd(&cnt[(u32)(t[k].payload >> shift) & mask], 1u);
         }
         __syncthreads();                                                     // B1: counts complete
-        {   // plan of this tile, one digit per thread (nbins <= 512 <= WC_THREADS): staged count m per digit,
+        {   // plan of this tile, one digit per thread (nbins <= 512 <= THREADS): staged count m per digit,
             // workgroup exclusive scan of m, then the per-digit routing words
             const u32 b = tid;
             u32 c = 0, m = 0;
@@ -589,7 +592,7 @@ k_scatter_wc(const Tup *__restrict__ in, Tup *__restrict__ out, const u64 *__res
         __syncthreads();                                                     // S2: plan visible
 #pragma unroll
         for (int k = 0; k < WC_TPT; k++) {
-            const u32 i = k * WC_THREADS + tid;
+            const u32 i = k * THREADS + tid;
             if (i < ntile) {
                 const u32 d = (u32)(t[k].payload >> shift) & mask;
                 const u32 p = P[d], heads = (p >> 16) & 0xfffu;
@@ -598,7 +601,7 @@ k_scatter_wc(const Tup *__restrict__ in, Tup *__restrict__ out, const u64 *__res
             }
         }
         __syncthreads();                                                     // D: cb heads + staging complete
-        for (u32 q = tid; q < nbins * 8; q += WC_THREADS) {                  // completed carry lines: 8 lanes = one 128 B line
+        for (u32 q = tid; q < nbins * 8; q += THREADS) {                  // completed carry lines: 8 lanes = one 128 B line
             const u32 d = q >> 3, j = q & 7;
             const u64 x = LB[d];
             if (x != ~0ull && j >= ((u32)x & 7u)) out[(x & ~7ull) + j] = cb[q];
@@ -607,7 +610,7 @@ k_scatter_wc(const Tup *__restrict__ in, Tup *__restrict__ out, const u64 *__res
         u32 keep = 0;
 #pragma unroll
         for (int k = 0; k < WC_TPT; k++) {
-            const u32 i = k * WC_THREADS + tid;
+            const u32 i = k * THREADS + tid;
             if (i < mt) {
                 const Tup v = tile[i];
                 const u32 d = (u32)(v.payload >> shift) & mask;
@@ -621,7 +624,7 @@ k_scatter_wc(const Tup *__restrict__ in, Tup *__restrict__ out, const u64 *__res
 #pragma unroll
             for (int k = 0; k < WC_TPT; k++) {
                 if (keep & (1u << k)) {
-                    const u32 i = k * WC_THREADS + tid;
+                    const u32 i = k * THREADS + tid;
                     const Tup v = tile[i];
                     const u32 d = (u32)(v.payload >> shift) & mask;
                     cb[d * 8 + ((u32)(A[d] + i) & 7u)] = v;
@@ -634,19 +637,19 @@ k_scatter_wc(const Tup *__restrict__ in, Tup *__restrict__ out, const u64 *__res
     u64 cur = beg;
     if (cur < end) load_tile(ta, cur);
     while (cur < end) {
-        u64 nxt = cur + WC_TILE;
+        u64 nxt = cur + TILE;
         if (nxt < end) load_tile(tb_, nxt);
         process(ta, cur);
         cur = nxt;
         if (cur >= end) break;
-        nxt = cur + WC_TILE;
+        nxt = cur + TILE;
         if (nxt < end) load_tile(ta, nxt);
         process(tb_, cur);
         cur = nxt;
     }
     __syncthreads();
     // unit end: the still incomplete line of every digit (shared with the next unit's first line)
-    for (u32 q = tid; q < nbins * 8; q += WC_THREADS) {
+    for (u32 q = tid; q < nbins * 8; q += THREADS) {
         const u32 d = q >> 3, j = q & 7;
         const u64 g = gnext[d];
         if (j >= LO[d] && j < ((u32)g & 7u)) out[(g & ~7ull) + j] = cb[q];
@@ -1044,10 +1047,17 @@ size_t part_lds_bytes(int bits)
     return (size_t)PART_TILE * 16 + nbins * (8 + 8 + 4 + 4);
 }
 
-static size_t wc_lds_bytes(int bits)
+static size_t wc_lds_bytes(int bits, int threads)
 {
     const size_t nbins = (size_t)1 << bits;
-    return (size_t)WC_TILE * 16 + nbins * (128 + 8 + 8 + 8 + 4 + 4 + 4) + 16 + (WC_THREADS / 64) * 4;
+    return (size_t)threads * WC_TPT * 16 + nbins * (128 + 8 + 8 + 8 + 4 + 4 + 4) + 16 + (size_t)(threads / 64) * 4;
+}
+
+static int wc_threads_for(int bits)
+{
+    static const int force = getenv("RHJ_WC_THREADS") ? atoi(getenv("RHJ_WC_THREADS")) : 0;   // tuning aid
+    if (force == 512 || force == 1024) return force;
+    return bits <= 8 ? WC_THREADS_SMALL : WC_THREADS;
 }
 
 constexpr int BJ2_THREADS = 1024, BJ2_CHUNK = 8448, BJ2_BUCKET_BITS = 12, BJ2_EPT = 4;
@@ -1064,8 +1074,10 @@ static void allow_big_lds()
     done = true;
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_scatter_units_pipe),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)part_lds_bytes(PART_MAX_BITS));
-    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_scatter_wc),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)wc_lds_bytes(WC_MAX_BITS));
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_scatter_wc<WC_THREADS>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)wc_lds_bytes(WC_MAX_BITS, WC_THREADS));
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_scatter_wc<WC_THREADS_SMALL>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)wc_lds_bytes(WC_MAX_BITS, WC_THREADS_SMALL));
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_join_bkt<BJ_THREADS, BJ_CHUNK, BJ_BUCKET_BITS, BJ_EPT>),
                               hipFuncAttributeMaxDynamicSharedMemorySize,
                               (int)bj_lds_bytes(BJ_THREADS, BJ_CHUNK, BJ_BUCKET_BITS));
@@ -1114,9 +1126,14 @@ void launch_scatter_units(hipStream_t st, const void *d_in, void *d_out, const P
     if (g.max_units == 0) return;
     allow_big_lds();
     if (g.bits <= WC_MAX_BITS) {
-        hipLaunchKernelGGL(k_scatter_wc, dim3(g.max_units), dim3(WC_THREADS), wc_lds_bytes(g.bits), st,
-                           (const Tup *)d_in, (Tup *)d_out, d_seg_start, d_unit_start, g.nseg, g.L, g.shift, g.bits,
-                           d_unit_base, (const u64 *)nullptr, 0u);
+        if (wc_threads_for(g.bits) == WC_THREADS_SMALL)
+            hipLaunchKernelGGL(k_scatter_wc<WC_THREADS_SMALL>, dim3(g.max_units), dim3(WC_THREADS_SMALL),
+                               wc_lds_bytes(g.bits, WC_THREADS_SMALL), st, (const Tup *)d_in, (Tup *)d_out, d_seg_start,
+                               d_unit_start, g.nseg, g.L, g.shift, g.bits, d_unit_base, (const u64 *)nullptr, 0u);
+        else
+            hipLaunchKernelGGL(k_scatter_wc<WC_THREADS>, dim3(g.max_units), dim3(WC_THREADS), wc_lds_bytes(g.bits, WC_THREADS),
+                               st, (const Tup *)d_in, (Tup *)d_out, d_seg_start, d_unit_start, g.nseg, g.L, g.shift, g.bits,
+                               d_unit_base, (const u64 *)nullptr, 0u);
         return;
     }
     // 10-bit pass: carry lines (2^10 x 128 B) do not fit LDS beside a tile -> tile-sort form
@@ -1155,8 +1172,14 @@ void launch_scatter_ranges(hipStream_t st, const void *d_in, void *d_out, u32 nu
 {
     if (nunits == 0) return;
     allow_big_lds();
-    hipLaunchKernelGGL(k_scatter_wc, dim3(nunits), dim3(WC_THREADS), wc_lds_bytes(bits), st, (const Tup *)d_in,
-                       (Tup *)d_out, (const u64 *)nullptr, (const u32 *)nullptr, 0u, (u64)0, shift, bits, d_unit_base, d_rng, nunits);
+    if (wc_threads_for(bits) == WC_THREADS_SMALL)
+        hipLaunchKernelGGL(k_scatter_wc<WC_THREADS_SMALL>, dim3(nunits), dim3(WC_THREADS_SMALL), wc_lds_bytes(bits, WC_THREADS_SMALL),
+                           st, (const Tup *)d_in, (Tup *)d_out, (const u64 *)nullptr, (const u32 *)nullptr, 0u, (u64)0, shift,
+                           bits, d_unit_base, d_rng, nunits);
+    else
+        hipLaunchKernelGGL(k_scatter_wc<WC_THREADS>, dim3(nunits), dim3(WC_THREADS), wc_lds_bytes(bits, WC_THREADS), st,
+                           (const Tup *)d_in, (Tup *)d_out, (const u64 *)nullptr, (const u32 *)nullptr, 0u, (u64)0, shift, bits,
+                           d_unit_base, d_rng, nunits);
 }
 
 void launch_diff_hist(hipStream_t st, const u64 *d_start, u64 nbins, u64 *d_hist)

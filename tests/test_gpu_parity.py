@@ -331,3 +331,49 @@ def test_concurrent_contexts(oracle):
         t.join()
     assert not errors, errors
     assert [r for r in results] == [c[2] for c in cases]
+
+
+def test_partition_at_owner_bits(engine, oracle):
+    """rhj_partition_at: one pass on arbitrary payload bits (the multi-GPU owner split)"""
+    n = 700_001
+    R = oracle.gen_R(n)
+    dR, dO, dP = engine.to_device(R), engine.alloc(16 * n), engine.alloc(8 * 9)
+    engine.partition_at(dR, n, 20, 3, dO, dP)
+    out, ps = dO.to_numpy(TUPLE, n), dP.to_numpy(np.uint64, 9)
+    dig = ((R["payload"] >> np.uint64(20)) & np.uint64(7)).astype(np.int64)
+    assert np.array_equal(ps, np.concatenate([[0], np.cumsum(np.bincount(dig, minlength=8))]).astype(np.uint64))
+    od = ((out["payload"] >> np.uint64(20)) & np.uint64(7)).astype(np.int64)
+    assert np.all(np.diff(od) >= 0)
+    assert np.array_equal(out[np.lexsort((out["key"], od))], R[np.lexsort((R["key"], dig))])
+
+
+def test_all_equal_keys_count_beyond_32_bits(engine, oracle):
+    """70,000 x 70,000 tuples with ONE join value: 4.9e9 pairs (> 2^32), counted exactly without materialising;
+    exercises chunked builds, the long-bucket path and 64-bit result counts."""
+    n = 70_000
+    dR, dS = engine.alloc(16 * n), engine.alloc(16 * n)
+    engine.generate(GEN_CONST, dR, n, 0, 12345)
+    engine.generate(GEN_CONST, dS, n, 0, 12345)
+    assert engine.join_dev(dR, n, dS, n) == n * n
+    # and a materialised prefix is made of valid pairs only
+    dO = engine.alloc(16 * 1_000_000)
+    assert engine.join_dev(dR, n, dS, n, dO, 1_000_000, allow_overflow=True) == n * n
+    part = dO.to_numpy(PAIR, 1_000_000)
+    assert part["keyR"].max() < n and part["keyS"].max() < n
+    assert len(np.unique(part["keyR"] * np.uint64(n) + part["keyS"])) == 1_000_000      # no pair twice
+
+
+@pytest.mark.parametrize("theta", [500, 990, 1250])
+def test_zipf_thetas(engine, oracle, theta):
+    nR, nS = 1_000_000, 4_000_000
+    dR, dS, dO = engine.alloc(16 * nR), engine.alloc(16 * nS), engine.alloc(16 * nS)
+    engine.generate(GEN_R, dR, nR, 0, nR)
+    engine.generate(GEN_S_ZIPF, dS, nS, 0, nR, seed=9, theta_milli=theta)
+    exp_n, exp_c = engine.expected_pkfk(dS, nS)
+    assert engine.join_dev(dR, nR, dS, nS, dO, nS) == exp_n == nS
+    assert engine.pairs_checksum(dO, nS) == exp_c
+    # swapped sides (skewed side is R): same pairs with the roles exchanged
+    S = dS.to_numpy(TUPLE, nS)
+    got = engine.join(S[:500_000], oracle.gen_R(nR)[:200_000])
+    exp = oracle.join(S[:500_000], oracle.gen_R(nR)[:200_000])
+    assert np.array_equal(sorted_pairs(got), sorted_pairs(exp))

@@ -154,6 +154,36 @@ int rhj_generate_dev(rhj_ctx *ctx, int kind, rhj_tuple *d_out, uint64_t n, uint6
  *   Computed by one streaming pass over S that inverts mix(); does not run the join. */
 int rhj_expected_pkfk_dev(rhj_ctx *ctx, const rhj_tuple *d_S, uint64_t n, uint64_t *count, uint64_t *checksum);
 
+/* ---- query-layer kernels (the steps immediately before and after the hot path) -------------
+ * With the columns of the stored relations resident in HBM these make a whole query device-resident:
+ * filters, join-input construction, intermediate-result maintenance and the SUM projections never
+ * cross PCIe; only counts and 8-byte sums reach the host.  All arrays are uint64 in HBM.  A NULL row list
+ * (d_rows / d_rowsA / d_rowsB / d_rows_in) stands for the identity 0..n-1 (an alias without filters).
+ *
+ * rhj_col_filter: the filter loops of Query::run_filters (Query.cpp:96-146).  d_rows_in == NULL means
+ *   "all rows 0..n_in-1".  Keeps the rows r with  d_col[r] <op> value,  op in {'<','>','='}; writes them
+ *   (unordered) to d_rows_out (capacity n_in) and their number to *n_out. */
+int rhj_col_filter(rhj_ctx *ctx, const uint64_t *d_col, const uint64_t *d_rows_in, uint64_t n_in, int op,
+                   uint64_t value, uint64_t *d_rows_out, uint64_t *n_out);
+/* rhj_gather_tuples: relation::foo / create_relation (structs.cpp:217-243) without the host round trip:
+ *   d_tuples[i] = { key = key_is_position ? i : d_rows[i],  payload = d_col[d_rows[i]] }.
+ *   key_is_position = 1 builds a POSITION-CARRYING join input: the join's pairs then name intermediate rows
+ *   directly, which replaces the de-duplication of structs.cpp:238-241 and the rescans of
+ *   intermediate.cpp:52-87 by one gather. */
+int rhj_gather_tuples(rhj_ctx *ctx, const uint64_t *d_col, const uint64_t *d_rows, uint64_t n, int key_is_position,
+                      rhj_tuple *d_tuples);
+/* rhj_pairs_split: getVector (intermediate.cpp:92-105): d_r[i] = pairs[i].keyR, d_s[i] = pairs[i].keyS */
+int rhj_pairs_split(rhj_ctx *ctx, const rhj_pair *d_pairs, uint64_t n, uint64_t *d_r, uint64_t *d_s);
+/* rhj_gather_u64: d_dst[i] = d_src[d_idx[i]]  (re-materialises one intermediate column after a join) */
+int rhj_gather_u64(rhj_ctx *ctx, const uint64_t *d_src, const uint64_t *d_idx, uint64_t n, uint64_t *d_dst);
+/* rhj_rows_filter_equal: a predicate between two aliases that are BOTH in the intermediate already
+ *   (intermediate.cpp:72-87,169-180) or a same-alias predicate (parse_table, intermediate.cpp:11-44):
+ *   keeps the positions e with d_colA[d_rowsA[e]] == d_colB[d_rowsB[e]] in d_pos_out (capacity n). */
+int rhj_rows_filter_equal(rhj_ctx *ctx, const uint64_t *d_colA, const uint64_t *d_rowsA, const uint64_t *d_colB,
+                          const uint64_t *d_rowsB, uint64_t n, uint64_t *d_pos_out, uint64_t *n_out);
+/* rhj_sum_gather: column_proj (Query.cpp:66-74): *sum = sum of d_col[d_rows[i]] (mod 2^64) */
+int rhj_sum_gather(rhj_ctx *ctx, const uint64_t *d_col, const uint64_t *d_rows, uint64_t n, uint64_t *sum);
+
 /* raw HBM helpers so a plain C/C++ host (no HIP headers) can use the device-resident API */
 int rhj_dev_alloc(rhj_ctx *ctx, uint64_t bytes, void **d_ptr);
 int rhj_dev_free(rhj_ctx *ctx, void *d_ptr);

@@ -72,6 +72,12 @@ SYMBOLS = {
     "rhj_pairs_checksum_dev": (C.c_int, [_vp, _vp, _u64, _P(_u64)]),
     "rhj_generate_dev": (C.c_int, [_vp, C.c_int, _vp, _u64, _u64, _u64, _u64, C.c_int]),
     "rhj_expected_pkfk_dev": (C.c_int, [_vp, _vp, _u64, _P(_u64), _P(_u64)]),
+    "rhj_col_filter": (C.c_int, [_vp, _vp, _vp, _u64, C.c_int, _u64, _vp, _P(_u64)]),
+    "rhj_gather_tuples": (C.c_int, [_vp, _vp, _vp, _u64, C.c_int, _vp]),
+    "rhj_pairs_split": (C.c_int, [_vp, _vp, _u64, _vp, _vp]),
+    "rhj_gather_u64": (C.c_int, [_vp, _vp, _vp, _u64, _vp]),
+    "rhj_rows_filter_equal": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _u64, _vp, _P(_u64)]),
+    "rhj_sum_gather": (C.c_int, [_vp, _vp, _vp, _u64, _P(_u64)]),
     "rhj_dev_alloc": (C.c_int, [_vp, _u64, _P(_vp)]),
     "rhj_dev_free": (C.c_int, [_vp, _vp]),
     "rhj_copy_h2d": (C.c_int, [_vp, _vp, _vp, _u64]),
@@ -261,6 +267,32 @@ class Engine:
                                       radix_bits, probe_split, _addr(d_out), capacity, C.byref(n))
         self._chk(rc, allow=(RHJ_E_OVERFLOW,) if allow_overflow else ())
         return n.value
+
+    # ---- query-layer kernels -------------------------------------------------------------
+    def col_filter(self, d_col, d_rows_in, n_in, op, value, d_rows_out):
+        n = _u64()
+        self._chk(self.lib.rhj_col_filter(self.ctx, _addr(d_col), _addr(d_rows_in), n_in, ord(op), value, _addr(d_rows_out), C.byref(n)))
+        return n.value
+
+    def gather_tuples(self, d_col, d_rows, n, key_is_position, d_tuples):
+        self._chk(self.lib.rhj_gather_tuples(self.ctx, _addr(d_col), _addr(d_rows), n, 1 if key_is_position else 0, _addr(d_tuples)))
+
+    def pairs_split(self, d_pairs, n, d_r, d_s):
+        self._chk(self.lib.rhj_pairs_split(self.ctx, _addr(d_pairs), n, _addr(d_r), _addr(d_s)))
+
+    def gather_u64(self, d_src, d_idx, n, d_dst):
+        self._chk(self.lib.rhj_gather_u64(self.ctx, _addr(d_src), _addr(d_idx), n, _addr(d_dst)))
+
+    def rows_filter_equal(self, d_colA, d_rowsA, d_colB, d_rowsB, n, d_pos_out):
+        m = _u64()
+        self._chk(self.lib.rhj_rows_filter_equal(self.ctx, _addr(d_colA), _addr(d_rowsA), _addr(d_colB), _addr(d_rowsB), n,
+                                                 _addr(d_pos_out), C.byref(m)))
+        return m.value
+
+    def sum_gather(self, d_col, d_rows, n):
+        s = _u64()
+        self._chk(self.lib.rhj_sum_gather(self.ctx, _addr(d_col), _addr(d_rows), n, C.byref(s)))
+        return s.value
 
     def pairs_checksum(self, d_pairs, n):
         c = _u64()

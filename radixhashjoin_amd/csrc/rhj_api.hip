@@ -447,6 +447,12 @@ int join_phase(rhj_ctx *ctx, void *d_out, u64 cap, u64 *out_count)
 
 }  // namespace
 
+// hooks for rhj_query.hip (same shared library, separate translation unit)
+int rhj_internal_use_device(rhj_ctx *ctx) { return use_device(ctx); }
+hipStream_t rhj_internal_stream(rhj_ctx *ctx) { return ctx->stream; }
+int rhj_internal_fail(rhj_ctx *ctx, int code, const char *msg) { return fail(ctx, code, msg); }
+void *rhj_internal_counters(rhj_ctx *ctx) { return ensure(ctx, ctx->counters, 64) == RHJ_OK ? ctx->counters.p : nullptr; }
+
 // =================================================================================================
 // C-ABI
 // =================================================================================================

@@ -335,6 +335,8 @@ void Query::run_joins(JobScheduler &js, vector<relList> &relations, FilteredRows
 
 void Query::execute(JobScheduler &js, vector<relList> &relations)
 {
+    static const bool device_mode = getenv("RHJ_QUERY_MODE") && std::string(getenv("RHJ_QUERY_MODE")) == "device";
+    if (device_mode) { execute_device(js, relations); return; }
     FilteredRows filtered;
     filtered_out = run_filters(relations, filtered);
     if (!filtered_out) run_joins(js, relations, filtered);

@@ -14,10 +14,10 @@ GOLD = os.path.join(ROOT, "tests", "golden")
 JOIN = os.path.join(ROOT, "radixhashjoin_amd", "host", "join_gpu")
 
 
-def run_small(tmp_path, threads_env=None):
+def run_small(tmp_path, mode="host"):
     assert os.path.exists(JOIN), "build with __graft_entry__.build()"
     log = tmp_path / "joins.log"
-    env = dict(os.environ, RHJ_JOIN_LOG=str(log))
+    env = dict(os.environ, RHJ_JOIN_LOG=str(log), RHJ_QUERY_MODE=mode)
     stdin = open(os.path.join(GOLD, "small", "small.init"), "rb").read() + open(os.path.join(GOLD, "small", "small.work"), "rb").read()
     out = subprocess.run([JOIN], input=stdin, cwd=GOLD, env=env, capture_output=True, timeout=600, check=True).stdout
     return out, log
@@ -32,3 +32,10 @@ def test_small_work_byte_identical(tmp_path, small_joins):
     got = collections.Counter(tuple(int(x) for x in line.split()) for line in open(log))
     assert sum(got.values()) == 94
     assert got == want                                            # the same 94 joins, same sizes, same match counts
+
+
+def test_small_work_device_resident_queries(tmp_path):
+    """the same workload with the whole query device-resident (RHJ_QUERY_MODE=device: columns in HBM, device
+    filters, position-carrying join inputs, gathered intermediates, device SUMs): same 50 lines"""
+    out, _ = run_small(tmp_path, mode="device")
+    assert out == open(os.path.join(GOLD, "small", "small.result"), "rb").read()

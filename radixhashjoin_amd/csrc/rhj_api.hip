@@ -417,16 +417,17 @@ int join_phase_on(rhj_ctx *ctx, const void *d_Rp, const u64 *d_psR, u64 nR, cons
         Span s(ctx, RHJ_K_AUX);
         HIPCHK(ctx, hipMemsetAsync(ctx->counters.p, 0, 64, ctx->stream));
     }
+    // average build partition larger than one 4224-tuple table (an explicit plan with too few bits,
+    // or heavy duplication): the one-workgroup-per-CU geometry with 8448-tuple tables re-probes half as often
+    const u64 nbuild = nR < nS ? nR : nS;
+    const bool big_tables = nbuild / nparts > (u64)BJ_CHUNK;
     {
         Span s(ctx, RHJ_K_TASKS);
-        launch_make_tasks(ctx->stream, d_psR, d_psS, nparts, probe_split, (JoinTask *)ctx->tasks.p, d_ntasks, max_tasks);
+        launch_make_tasks(ctx->stream, d_psR, d_psS, nparts, probe_split, (JoinTask *)ctx->tasks.p, d_ntasks, max_tasks,
+                          d_count + 2, big_tables);                 // counters[2..3]: largest partition of R, S
     }
     {
         Span s(ctx, RHJ_K_JOIN);
-        // average build partition larger than one 4224-tuple table (an explicit plan with too few bits,
-        // or heavy duplication): the one-workgroup-per-CU geometry with 8448-tuple tables re-probes half as often
-        const u64 nbuild = nR < nS ? nR : nS;
-        const bool big_tables = nbuild / nparts > (u64)BJ_CHUNK;
         launch_join(ctx->stream, d_Rp, d_psR, d_Sp, d_psS, (const JoinTask *)ctx->tasks.p, d_ntasks, max_tasks,
                     radix_bits, d_out, d_out ? cap : 0, d_count, big_tables);
     }

@@ -55,7 +55,7 @@ void launch_scatter_units(hipStream_t st, const void *d_in, void *d_out, const P
 void launch_diff_hist(hipStream_t st, const u64 *d_start, u64 nbins, u64 *d_hist);
 void launch_prefix(hipStream_t st, const u64 *d_hist, u64 nbins, u64 *d_start);
 void launch_make_tasks(hipStream_t st, const u64 *d_startR, const u64 *d_startS, u64 nparts, u32 probe_split,
-                       JoinTask *d_tasks, u32 *d_ntasks, u32 max_tasks);
+                       JoinTask *d_tasks, u32 *d_ntasks, u32 max_tasks, u64 *d_stats, bool big_tables);
 void launch_join(hipStream_t st, const void *d_R, const u64 *d_startR, const void *d_S, const u64 *d_startS,
                  const JoinTask *d_tasks, const u32 *d_ntasks, u32 grid, int radix_bits,
                  void *d_out, u64 out_capacity, u64 *d_out_count, bool big_tables);

@@ -699,9 +699,29 @@ __global__ void __launch_bounds__(1024) k_prefix(const u64 *__restrict__ hist, u
 // (probe-side load balance under skew).  Build side = S when |R_k| >= |S_k| (JobScheduler.cpp:187).
 // One atomic per workgroup reserves its tasks' slots.
 // ------------------------------------------------------------------------------------------------
+// largest partition of each side (skew indicator for k_make_tasks): stats[0] = max |R_k|, stats[1] = max |S_k|
+__global__ void __launch_bounds__(256)
+k_part_max(const u64 *__restrict__ startR, const u64 *__restrict__ startS, u64 nparts, u64 *__restrict__ stats)
+{
+    u64 mr = 0, ms = 0;
+    for (u64 k = (u64)blockIdx.x * 256 + threadIdx.x; k < nparts; k += (u64)gridDim.x * 256) {
+        const u64 a = startR[k + 1] - startR[k], b = startS[k + 1] - startS[k];
+        mr = a > mr ? a : mr;
+        ms = b > ms ? b : ms;
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        const u64 a = __shfl_down(mr, off, 64), b = __shfl_down(ms, off, 64);
+        mr = a > mr ? a : mr;
+        ms = b > ms ? b : ms;
+    }
+    if ((threadIdx.x & 63) == 0) { atomicMax(&stats[0], mr); atomicMax(&stats[1], ms); }
+}
+
 __global__ void __launch_bounds__(1024)
 k_make_tasks(const u64 *__restrict__ startR, const u64 *__restrict__ startS, u64 nparts, u32 probe_split,
-             JoinTask *__restrict__ tasks, u32 *__restrict__ ntasks, u32 max_tasks)
+             JoinTask *__restrict__ tasks, u32 *__restrict__ ntasks, u32 max_tasks, const u64 *__restrict__ stats,
+             u32 table_tuples)
 {
     __shared__ u32 wsum[16];
     __shared__ u32 gbase;
@@ -711,8 +731,18 @@ k_make_tasks(const u64 *__restrict__ startR, const u64 *__restrict__ startS, u64
     if (k < nparts) {
         const u64 r0 = startR[k], nr = startR[k + 1] - r0, s0 = startS[k], ns = startS[k + 1] - s0;
         if (nr != 0 && ns != 0) {
-            if (nr >= ns) { pbeg = r0; plen = nr; bbeg = s0; blen = ns; bis = 1; }
-            else          { pbeg = s0; plen = ns; bbeg = r0; blen = nr; bis = 0; }
+            // Reference rule: build on the smaller bucket (S when |R_k| >= |S_k|, JobScheduler.cpp:187).  Exception:
+            // when ONE relation's partition sizes are heavily skewed (its largest partition > 16x the mean: repeated
+            // join values, e.g. a Zipf foreign key) and the other's are balanced, its small partitions are small
+            // tables full of duplicates: long buckets that serialise the few probe lanes hitting them.  If the
+            // balanced side fits one LDS table, build on it instead: one-compare probes, same pairs.
+            const u64 meanR = startR[nparts] / nparts + 1, meanS = startS[nparts] / nparts + 1;
+            const bool skewR = stats[0] > 16 * meanR, skewS = stats[1] > 16 * meanS;
+            bool build_S = nr >= ns;
+            if (skewS && !skewR && nr <= table_tuples) build_S = false;
+            if (skewR && !skewS && ns <= table_tuples) build_S = true;
+            if (build_S) { pbeg = r0; plen = nr; bbeg = s0; blen = ns; bis = 1; }
+            else         { pbeg = s0; plen = ns; bbeg = r0; blen = nr; bis = 0; }
             nt = (u32)((plen + probe_split - 1) / probe_split);
         }
     }
@@ -1193,10 +1223,14 @@ void launch_prefix(hipStream_t st, const u64 *d_hist, u64 nbins, u64 *d_start)
 }
 
 void launch_make_tasks(hipStream_t st, const u64 *d_startR, const u64 *d_startS, u64 nparts, u32 probe_split,
-                       JoinTask *d_tasks, u32 *d_ntasks, u32 max_tasks)
+                       JoinTask *d_tasks, u32 *d_ntasks, u32 max_tasks, u64 *d_stats, bool big_tables)
 {
+    u64 g = (nparts + 255) / 256;
+    if (g > 1024) g = 1024;
+    hipLaunchKernelGGL(k_part_max, dim3((unsigned)g), dim3(256), 0, st, d_startR, d_startS, nparts, d_stats);   // d_stats zeroed by the caller
     hipLaunchKernelGGL(k_make_tasks, dim3((unsigned)((nparts + 1023) / 1024)), dim3(1024), 0, st, d_startR, d_startS,
-                       nparts, probe_split, d_tasks, d_ntasks, max_tasks);
+                       nparts, probe_split, d_tasks, d_ntasks, max_tasks, (const u64 *)d_stats,
+                       (u32)(big_tables ? BJ2_CHUNK : BJ_CHUNK));
 }
 
 void launch_join(hipStream_t st, const void *d_R, const u64 *d_startR, const void *d_S, const u64 *d_startS,

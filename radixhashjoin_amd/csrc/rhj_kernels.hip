@@ -735,12 +735,12 @@ k_make_tasks(const u64 *__restrict__ startR, const u64 *__restrict__ startS, u64
             // when ONE relation's partition sizes are heavily skewed (its largest partition > 16x the mean: repeated
             // join values, e.g. a Zipf foreign key) and the other's are balanced, its small partitions are small
             // tables full of duplicates: long buckets that serialise the few probe lanes hitting them.  If the
-            // balanced side fits one LDS table, build on it instead: one-compare probes, same pairs.
+            // balanced side fits one or two LDS tables, build on it instead: one-compare probes, same pairs.
             const u64 meanR = startR[nparts] / nparts + 1, meanS = startS[nparts] / nparts + 1;
             const bool skewR = stats[0] > 16 * meanR, skewS = stats[1] > 16 * meanS;
             bool build_S = nr >= ns;
-            if (skewS && !skewR && nr <= table_tuples) build_S = false;
-            if (skewR && !skewS && ns <= table_tuples) build_S = true;
+            if (skewS && !skewR && nr <= 2 * (u64)table_tuples) build_S = false;     // at most two build chunks
+            if (skewR && !skewS && ns <= 2 * (u64)table_tuples) build_S = true;
             if (build_S) { pbeg = r0; plen = nr; bbeg = s0; blen = ns; bis = 1; }
             else         { pbeg = s0; plen = ns; bbeg = r0; blen = nr; bis = 0; }
             nt = (u32)((plen + probe_split - 1) / probe_split);

@@ -211,7 +211,9 @@ int resolve_plan(u64 nR, u64 nS, const rhj_opts *in, rhj_opts *out)
             if (bits == 0) o.passes = 0;
             else if (bits <= 9) { o.passes = 1; o.bits1 = bits; }
             else {
-                if (bits > 2 * PART_MAX_BITS) bits = 2 * PART_MAX_BITS;
+                // 9 bits per pass is the widest line-aligned write-combining scatter; beyond 18 bits the bucket join's
+                // 8448-tuple geometry / build chunks absorb the larger partitions (10-bit passes run at half the rate)
+                if (bits > 18) bits = 18;
                 o.passes = 2; o.bits1 = (bits + 1) / 2; o.bits2 = bits / 2;
             }
         }

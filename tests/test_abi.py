@@ -46,6 +46,8 @@ def test_plan_auto():
     assert p.passes == 2 and p.bits1 + p.bits2 == 18    # avg build partition 3815 <= 15/16 * 4224
     p = P(10**9, 10**9, O(2, 8, 8))
     assert (p.passes, p.bits1, p.bits2) == (2, 8, 8)    # BASELINE config 3 as named
+    p = P(8 * 10**9, 8 * 10**9)
+    assert (p.passes, p.bits1, p.bits2) == (2, 9, 9)    # never plans a 10-bit pass: the bucket join chunks instead
     assert P(10**9, 5).passes == 0
     for bad in (O(3, 0, 0), O(1, 12, 0), O(2, 8, -1)):
         with pytest.raises(rhj.RhjError):

@@ -1,0 +1,79 @@
+#!/usr/bin/env python3
+"""tools/fuzz.py -- randomized differential test of the HIP path against the CPU oracle (development aid).
+Random sizes (incl. tile/unit/table boundaries), value domains, duplicate structure, skew, radix plans and
+probe splits; compares (count, checksum) and, for small outputs, the sorted pair sets.  python tools/fuzz.py [seconds]"""
+import os, sys, time
+import numpy as np
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import radixhashjoin_amd as rhj
+from oracle.pyoracle import Oracle, TUPLE, sorted_pairs
+
+budget = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
+seed = int(sys.argv[2]) if len(sys.argv) > 2 else 12345
+rng = np.random.default_rng(seed)
+o, e = Oracle(), rhj.Engine(0)
+EDGE = [1, 2, 7, 8, 9, 63, 64, 65, 2047, 2048, 2049, 4095, 4096, 4097, 4223, 4224, 4225, 8447, 8448, 8449, 32767, 32768, 32769]
+
+
+def size():
+    r = rng.random()
+    if r < 0.35:
+        return int(rng.choice(EDGE))
+    if r < 0.8:
+        return int(rng.integers(1, 200_000))
+    return int(rng.integers(200_000, 3_000_000))
+
+
+def rel(n, dom, skew, key0):
+    t = np.empty(n, dtype=TUPLE)
+    t["key"] = rng.permutation(n).astype(np.uint64) + np.uint64(key0)
+    if skew == 0:
+        v = rng.integers(0, dom, n, dtype=np.uint64)
+    elif skew == 1:      # power-law ranks
+        v = (rng.pareto(1.1, n) * 3).astype(np.uint64) % np.uint64(dom)
+    else:                # one hot value + uniform rest
+        v = rng.integers(0, dom, n, dtype=np.uint64)
+        v[rng.random(n) < 0.5] = np.uint64(dom // 2)
+    mode = rng.integers(0, 3)
+    if mode == 1:
+        v = v * np.uint64(0x9E3779B97F4A7C15)            # spread the values over all 64 bits (bijective)
+    elif mode == 2:
+        v = v << np.uint64(rng.integers(0, 40))
+    t["payload"] = v
+    return t
+
+
+t0, cases, maxout = time.time(), 0, 0
+while time.time() - t0 < budget:
+    nR, nS = size(), size()
+    dom = int(rng.choice([1, 2, 5, 100, 4096, 70_000, 1 << 22, 1 << 40]))
+    skR, skS = int(rng.integers(0, 3)), int(rng.integers(0, 3))
+    R, S = rel(nR, dom, skR, 0), rel(nS, dom, skS, 10**7)
+    # expected output size first (value counts), so that neither the oracle nor the GPU materialises a huge result
+    vr, cr = np.unique(R["payload"], return_counts=True)
+    vs, cs = np.unique(S["payload"], return_counts=True)
+    common, ir, is_ = np.intersect1d(vr, vs, assume_unique=True, return_indices=True)
+    est = int((cr[ir].astype(np.float64) * cs[is_].astype(np.float64)).sum())
+    if est > 20_000_000:
+        continue
+    exp_n, exp_c = o.join_count_checksum(R, S)
+    assert exp_n == est
+    r = rng.random()
+    if r < 0.4:
+        opts = None
+    elif r < 0.55:
+        opts = rhj.Opts(0, 0, 0, int(rng.choice([0, 4096, 8192])))
+    elif r < 0.75:
+        opts = rhj.Opts(1, int(rng.integers(1, 11)), 0, int(rng.choice([0, 4096])))
+    else:
+        opts = rhj.Opts(2, int(rng.integers(1, 11)), int(rng.integers(1, 11)), int(rng.choice([0, 4096, 32768])))
+    got = e.join(R, S, opts=opts)
+    ok = (len(got), o.pairs_checksum(got)) == (exp_n, exp_c)
+    if ok and exp_n <= 300_000:
+        ok = np.array_equal(sorted_pairs(got), sorted_pairs(o.join(R, S)))
+    if not ok:
+        print("MISMATCH", dict(nR=nR, nS=nS, dom=dom, skR=skR, skS=skS, opts=opts, got=len(got), exp=exp_n, seed=seed, case=cases), flush=True)
+        sys.exit(1)
+    cases += 1
+    maxout = max(maxout, exp_n)
+print(f"fuzz ok: {cases} random joins in {time.time() - t0:.0f} s, largest output {maxout} pairs, seed {seed}")

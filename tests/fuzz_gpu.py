@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
-"""tools/fuzz.py -- randomized differential test of the HIP path against the CPU oracle (development aid).
+"""tests/fuzz_gpu.py -- randomized differential test of the HIP path against the CPU oracle (run by hand on the GPU box).
 Random sizes (incl. tile/unit/table boundaries), value domains, duplicate structure, skew, radix plans and
-probe splits; compares (count, checksum) and, for small outputs, the sorted pair sets.  python tools/fuzz.py [seconds]"""
+probe splits; compares (count, checksum) and, for small outputs, the sorted pair sets.  python tests/fuzz_gpu.py [seconds] [seed]"""
 import os, sys, time
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))

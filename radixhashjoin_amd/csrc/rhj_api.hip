@@ -250,8 +250,10 @@ PassGeom make_geom(u64 n, u32 nseg, int shift, int bits)
 }
 
 // One partition pass over all segments: histogram -> scan -> scatter.
+// `whole_relation`: the pass has ONE segment [0,n) and d_seg_start is this context's seg0 buffer, which the pass then
+// fills together with the unit table in one launch.
 int run_pass(rhj_ctx *ctx, const void *d_in, void *d_out, u64 n, const u64 *d_seg_start, u32 nseg, int shift,
-             int bits, u64 *d_part_start)
+             int bits, u64 *d_part_start, bool whole_relation = false)
 {
     const PassGeom g = make_geom(n, nseg, shift, bits);
     const size_t nbins = (size_t)1 << bits;
@@ -262,7 +264,8 @@ int run_pass(rhj_ctx *ctx, const void *d_in, void *d_out, u64 n, const u64 *d_se
     u32 *unit_start = (u32 *)ctx->unit_start.p;
     {
         Span s(ctx, RHJ_K_AUX);
-        launch_make_units(ctx->stream, d_seg_start, nseg, g.L, unit_start);
+        if (whole_relation) launch_init_single_segment(ctx->stream, n, g.L, (u64 *)ctx->seg0.p, unit_start);
+        else launch_make_units(ctx->stream, d_seg_start, nseg, g.L, unit_start);
     }
     {
         Span s(ctx, RHJ_K_HIST);
@@ -347,16 +350,11 @@ int partition_relation(rhj_ctx *ctx, const void *d_in, u64 n, int passes, int b1
     if (passes == 2 && fused_two_pass_ok(b1, b2) && n > 0 && n < ((u64)1 << 32))
         return partition_relation_fused(ctx, d_in, n, b1, b2, d_out, d_ps);
     RHJCHK(ensure(ctx, ctx->seg0, 64));
-    u64 *seg0 = (u64 *)ctx->seg0.p;
-    {
-        Span s(ctx, RHJ_K_AUX);
-        // seg0 = {0, n}; the u32 pair behind it is scratch
-        launch_init_single_segment(ctx->stream, n, PART_TILE, seg0, (u32 *)(seg0 + 4));
-    }
-    if (passes == 1) return run_pass(ctx, d_in, d_out, n, seg0, 1, 0, b1, d_ps);
+    u64 *seg0 = (u64 *)ctx->seg0.p;                 // {0, n}: written by the first pass itself
+    if (passes == 1) return run_pass(ctx, d_in, d_out, n, seg0, 1, 0, b1, d_ps, true);
     RHJCHK(ensure(ctx, ctx->part_tmp, (size_t)(n ? n : 1) * 16));
     RHJCHK(ensure(ctx, ctx->ps_1, (((size_t)1 << b1) + 1) * 8));
-    RHJCHK(run_pass(ctx, d_in, ctx->part_tmp.p, n, seg0, 1, 0, b1, (u64 *)ctx->ps_1.p));
+    RHJCHK(run_pass(ctx, d_in, ctx->part_tmp.p, n, seg0, 1, 0, b1, (u64 *)ctx->ps_1.p, true));
     return run_pass(ctx, ctx->part_tmp.p, d_out, n, (const u64 *)ctx->ps_1.p, 1u << b1, b1, b2, d_ps);
 }
 
@@ -673,12 +671,7 @@ int rhj_partition_at(rhj_ctx *ctx, const rhj_tuple *d_in, uint64_t n, int shift,
         return fail(ctx, RHJ_E_INVALID, "bad rhj_partition_at argument");
     prof_reset(ctx);
     RHJCHK(ensure(ctx, ctx->seg0, 64));
-    u64 *seg0 = (u64 *)ctx->seg0.p;
-    {
-        Span s(ctx, RHJ_K_AUX);
-        launch_init_single_segment(ctx->stream, n, PART_TILE, seg0, (u32 *)(seg0 + 4));
-    }
-    return run_pass(ctx, d_in, d_out, n, seg0, 1, shift, bits, (u64 *)d_part_start);
+    return run_pass(ctx, d_in, d_out, n, (const u64 *)ctx->seg0.p, 1, shift, bits, (u64 *)d_part_start, true);
 }
 
 int rhj_histogram(rhj_ctx *ctx, const rhj_tuple *d_rel, uint64_t n, int shift, int bits, uint64_t *d_hist)

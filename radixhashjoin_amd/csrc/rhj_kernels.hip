@@ -1097,11 +1097,13 @@ static size_t bj_lds_bytes(int threads, int chunk, int bbits)
     return (size_t)chunk * 16 + ((size_t)(1 << bbits) + 4) * 4 + 64 * 4 + (size_t)(threads / 64) * 4 + 16;
 }
 
-static void allow_big_lds()
+static void allow_big_lds()          // per device: a process may drive several GPUs through different contexts
 {
-    static bool done = false;
-    if (done) return;
-    done = true;
+    static bool done[64] = {};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
+    if (done[dev]) return;
+    done[dev] = true;
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_scatter_units_pipe),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)part_lds_bytes(PART_MAX_BITS));
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_scatter_wc<WC_THREADS>),
@@ -1177,10 +1179,12 @@ bool fused_two_pass_ok(int b1, int b2) { return b1 >= 1 && b2 >= 1 && b1 <= WC_M
 void launch_hist2d_units(hipStream_t st, const void *d_in, u64 n, u64 L, u32 units, int b1, int b2,
                          u32 units_per_group, u32 ngroups, u32 *d_hist1, u32 *d_hist2)
 {
-    static bool once = false;
+    static bool once[64] = {};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
     const size_t lds = ((size_t)1 << (b1 + b2)) * 2 + ((size_t)4 << b1);
-    if (!once) {
-        once = true;
+    if (!once[dev]) {
+        once[dev] = true;
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_hist2d_units),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)(((size_t)1 << 16) * 2 + ((size_t)4 << WC_MAX_BITS)));
     }

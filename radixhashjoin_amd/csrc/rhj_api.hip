@@ -9,6 +9,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <string>
+#include <sys/mman.h>
 #include <thread>
 #include <vector>
 
@@ -644,6 +645,13 @@ int rhj_join(rhj_ctx *ctx, const rhj_tuple *R, uint64_t nR, const rhj_tuple *S, 
     if (count == 0) return RHJ_OK;                    // head stays nullptr (Result::isEmpty)
     unsigned char *page = (unsigned char *)malloc(8 + (size_t)count * 16);
     if (!page) return fail(ctx, RHJ_E_NOMEM, "malloc of the result page failed");
+    if ((size_t)count * 16 >= ((size_t)64 << 20)) {
+        // a large result page is fresh mmap'd memory: ask for transparent huge pages so that the device-to-host
+        // copy takes one fault per 2 MiB instead of one per 4 KiB (the page stays an ordinary free()-able block)
+        const uintptr_t lo = ((uintptr_t)page + ((uintptr_t)2 << 20) - 1) & ~(((uintptr_t)2 << 20) - 1);
+        const uintptr_t hi = ((uintptr_t)page + 8 + (size_t)count * 16) & ~(((uintptr_t)2 << 20) - 1);
+        if (hi > lo) (void)madvise((void *)lo, hi - lo, MADV_HUGEPAGE);
+    }
     memset(page, 0, 8);                               // bucket_info::next = nullptr (Result.h:14-17)
     HIPCHK(ctx, hipMemcpyAsync(page + 8, ctx->out_pairs.p, (size_t)count * 16, hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));

@@ -162,6 +162,10 @@ void Query::execute_device(JobScheduler &js, std::vector<relList> &relations)
         OK(ctx, rhj_pairs_split(ctx, (const rhj_pair *)pairs.p, m, kr.p, ks.p));
         kr.n = ks.n = m;
         if (!in1 && !in2) {                            // case 1: the pairs become the two columns
+            // (a join between two aliases that are both new while OTHER aliases are already joined would need a
+            //  cross product; the reference's update_intermediate drops the older columns in that case
+            //  (intermediate.cpp:147-162: only table1/table2 of intermediate_upd are filled) -- same here)
+            for (DevArr &c : inter) c.reset();
             inter[j.table1] = std::move(kr);
             inter[j.table2] = std::move(ks);
         } else if (in1) {                              // case 2: keyR = intermediate row, keyS = new alias' rowID

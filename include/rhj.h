@@ -184,7 +184,9 @@ int rhj_rows_filter_equal(rhj_ctx *ctx, const uint64_t *d_colA, const uint64_t *
 /* rhj_sum_gather: column_proj (Query.cpp:66-74): *sum = sum of d_col[d_rows[i]] (mod 2^64) */
 int rhj_sum_gather(rhj_ctx *ctx, const uint64_t *d_col, const uint64_t *d_rows, uint64_t n, uint64_t *sum);
 
-/* raw HBM helpers so a plain C/C++ host (no HIP headers) can use the device-resident API */
+/* raw HBM helpers so a plain C/C++ host (no HIP headers) can use the device-resident API.  rhj_dev_free must be
+ * given the context that allocated the block; released blocks are kept by the context for re-use (its work is
+ * ordered on one stream) and go back to the device with rhj_release_workspace / rhj_destroy. */
 int rhj_dev_alloc(rhj_ctx *ctx, uint64_t bytes, void **d_ptr);
 int rhj_dev_free(rhj_ctx *ctx, void *d_ptr);
 int rhj_copy_h2d(rhj_ctx *ctx, void *d_dst, const void *src, uint64_t bytes);

@@ -8,6 +8,8 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <map>
+#include <mutex>
 #include <string>
 #include <sys/mman.h>
 #include <thread>
@@ -46,6 +48,11 @@ struct rhj_ctx {
     DevBuf tasks, counters;            // counters: [0] u64 out_count, [1] u32 ntasks (+pad), [2] u64 checksum
     DevBuf out_pairs;                  // rhj_join's device result buffer
     DevBuf hist_tmp, scan_tmp, hist2, grp_rng, unit_start2;
+    // rhj_dev_alloc / rhj_dev_free keep released blocks for re-use (all work of a context is ordered on its one
+    // stream, so a block may be handed out again while kernels that used it are still queued): a device-resident
+    // query allocates and frees a dozen arrays per join, and hipMalloc/hipFree would synchronise every time
+    std::vector<std::pair<void *, size_t>> free_blocks;
+    size_t free_bytes = 0;
     // pinned staging for host -> HBM copies of pageable caller memory (rhj_join)
     void *stage[2] = {nullptr, nullptr};
     hipEvent_t stage_ev[2] = {nullptr, nullptr};
@@ -449,6 +456,9 @@ int join_phase(rhj_ctx *ctx, void *d_out, u64 cap, u64 *out_count)
 
 }  // namespace
 
+static std::mutex g_pool_sizes_mu;
+static std::map<void *, size_t> g_pool_sizes;             // size of every live rhj_dev_alloc block (all contexts)
+
 // hooks for rhj_query.hip (same shared library, separate translation unit)
 int rhj_internal_use_device(rhj_ctx *ctx) { return use_device(ctx); }
 hipStream_t rhj_internal_stream(rhj_ctx *ctx) { return ctx->stream; }
@@ -518,6 +528,12 @@ int rhj_release_workspace(rhj_ctx *ctx)
                      &ctx->counters, &ctx->out_pairs, &ctx->hist_tmp, &ctx->scan_tmp, &ctx->hist2,
                      &ctx->grp_rng, &ctx->unit_start2};
     for (DevBuf *b : all) release(*b);
+    for (auto &b : ctx->free_blocks) {
+        { std::lock_guard<std::mutex> lk(g_pool_sizes_mu); g_pool_sizes.erase(b.first); }
+        (void)hipFree(b.first);
+    }
+    ctx->free_blocks.clear();
+    ctx->free_bytes = 0;
     for (int i = 0; i < 2; i++) {
         if (ctx->stage[i]) { (void)hipHostFree(ctx->stage[i]); ctx->stage[i] = nullptr; }
         if (ctx->stage_ev[i]) { (void)hipEventDestroy(ctx->stage_ev[i]); ctx->stage_ev[i] = nullptr; }
@@ -843,24 +859,70 @@ int rhj_generate_dev(rhj_ctx *ctx, int kind, rhj_tuple *d_out, uint64_t n, uint6
     return check_launch(ctx, "rhj_generate_dev");
 }
 
+// block sizes are rounded up (64 KiB steps, 1/8 steps above 8 MiB) so that released blocks fit later requests
+static size_t pool_round(uint64_t bytes)
+{
+    size_t b = bytes ? (size_t)bytes : 16;
+    size_t step = (size_t)64 << 10;
+    while (step * 8 < b) step <<= 1;
+    return (b + step - 1) / step * step;
+}
+constexpr size_t POOL_KEEP_BYTES = (size_t)8 << 30;       // released blocks kept per context at most
+
 int rhj_dev_alloc(rhj_ctx *ctx, uint64_t bytes, void **d_ptr)
 {
     RHJCHK(use_device(ctx));
     if (!d_ptr) return fail(ctx, RHJ_E_INVALID, "d_ptr is null");
     *d_ptr = nullptr;
-    hipError_t e = hipMalloc(d_ptr, bytes ? bytes : 16);
+    const size_t want = pool_round(bytes);
+    size_t best = (size_t)-1;
+    for (size_t i = 0; i < ctx->free_blocks.size(); i++)
+        if (ctx->free_blocks[i].second == want) { best = i; break; }
+    if (best != (size_t)-1) {
+        *d_ptr = ctx->free_blocks[best].first;
+        ctx->free_bytes -= want;
+        ctx->free_blocks[best] = ctx->free_blocks.back();
+        ctx->free_blocks.pop_back();
+        return RHJ_OK;
+    }
+    hipError_t e = hipMalloc(d_ptr, want);
+    if (e != hipSuccess && !ctx->free_blocks.empty()) {           // make room and try once more
+        (void)hipGetLastError();
+        for (auto &b : ctx->free_blocks) {
+            { std::lock_guard<std::mutex> lk(g_pool_sizes_mu); g_pool_sizes.erase(b.first); }
+            (void)hipFree(b.first);
+        }
+        ctx->free_blocks.clear();
+        ctx->free_bytes = 0;
+        e = hipMalloc(d_ptr, want);
+    }
     if (e != hipSuccess) {
         (void)hipGetLastError();
         *d_ptr = nullptr;
         return fail(ctx, RHJ_E_NOMEM, std::string("hipMalloc: ") + hipGetErrorString(e));
     }
+    std::lock_guard<std::mutex> lk(g_pool_sizes_mu);
+    g_pool_sizes[*d_ptr] = want;
     return RHJ_OK;
 }
 
 int rhj_dev_free(rhj_ctx *ctx, void *d_ptr)
 {
     RHJCHK(use_device(ctx));
-    if (d_ptr) HIPCHK(ctx, hipFree(d_ptr));
+    if (!d_ptr) return RHJ_OK;
+    size_t sz = 0;
+    {
+        std::lock_guard<std::mutex> lk(g_pool_sizes_mu);
+        auto it = g_pool_sizes.find(d_ptr);
+        if (it != g_pool_sizes.end()) sz = it->second;
+    }
+    if (sz && ctx->free_bytes + sz <= POOL_KEEP_BYTES && ctx->free_blocks.size() < 256) {
+        ctx->free_blocks.emplace_back(d_ptr, sz);                 // kept for re-use; returned to the device by
+        ctx->free_bytes += sz;                                    // rhj_release_workspace / rhj_destroy
+        return RHJ_OK;
+    }
+    { std::lock_guard<std::mutex> lk(g_pool_sizes_mu); g_pool_sizes.erase(d_ptr); }
+    HIPCHK(ctx, hipFree(d_ptr));
     return RHJ_OK;
 }
 

@@ -377,3 +377,19 @@ def test_zipf_thetas(engine, oracle, theta):
     got = engine.join(S[:500_000], oracle.gen_R(nR)[:200_000])
     exp = oracle.join(S[:500_000], oracle.gen_R(nR)[:200_000])
     assert np.array_equal(sorted_pairs(got), sorted_pairs(exp))
+
+
+def test_dev_alloc_recycles_blocks(engine):
+    """rhj_dev_free keeps blocks for re-use by the same context; rhj_release_workspace returns them to the device"""
+    a = engine.alloc(3_000_000)
+    pa = a.ptr
+    a.free()
+    b = engine.alloc(3_000_001)                 # same rounded size class: the released block comes back
+    assert b.ptr == pa
+    b.free()
+    free0, _ = engine.mem_info()
+    engine.release_workspace()
+    free1, _ = engine.mem_info()
+    assert free1 >= free0
+    c = engine.alloc(3_000_000)                 # still usable after the flush
+    c.free()

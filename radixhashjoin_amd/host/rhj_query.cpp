@@ -335,8 +335,11 @@ void Query::run_joins(JobScheduler &js, vector<relList> &relations, FilteredRows
 
 void Query::execute(JobScheduler &js, vector<relList> &relations)
 {
-    static const bool device_mode = getenv("RHJ_QUERY_MODE") && std::string(getenv("RHJ_QUERY_MODE")) == "device";
-    if (device_mode) { execute_device(js, relations); return; }
+    // default: the whole query device-resident (rhj_query_dev.cpp); RHJ_QUERY_MODE=host keeps filters and
+    // intermediates on the host and sends every equi-join through Result::multiRadixHashJoin with exactly the
+    // join inputs the reference builds
+    static const bool host_mode = getenv("RHJ_QUERY_MODE") && std::string(getenv("RHJ_QUERY_MODE")) == "host";
+    if (!host_mode) { execute_device(js, relations); return; }
     FilteredRows filtered;
     filtered_out = run_filters(relations, filtered);
     if (!filtered_out) run_joins(js, relations, filtered);

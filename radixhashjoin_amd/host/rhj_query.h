@@ -72,8 +72,8 @@ struct Query {                                /* Query.h:34-59 */
     void read_predicates();
     void read_projections();
     void execute(JobScheduler &js, std::vector<relList> &relations);
-    /* the same query executed device-resident (rhj_query_dev.cpp); execute() dispatches to it when
-       $RHJ_QUERY_MODE == "device" */
+    /* the same query executed device-resident (rhj_query_dev.cpp): what execute() does unless
+       $RHJ_QUERY_MODE == "host" */
     void execute_device(JobScheduler &js, std::vector<relList> &relations);
     bool run_filters(std::vector<relList> &relations,
                      std::unordered_map<uint64_t, std::unordered_set<uint64_t> > &filtered);

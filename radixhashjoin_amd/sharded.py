@@ -106,6 +106,7 @@ class ShardedJoin:
         plan = self._plan(mR, mS)
         dev = R.device
         Rx, _ = self.finish_exchange(hR)
+        hR = stagedR = None                                    # the send buffer of R can be recycled now
         if plan.passes == 0 or mR == 0 or mS == 0:
             Sx, _ = self.finish_exchange(hS)
             return self._local_join_whole(Rx, mR, Sx, mS, out)
@@ -117,6 +118,7 @@ class ShardedJoin:
         self.engine.partition(Rx, mR, b1, b2, partR, psR)      # local radix passes over R overlap the S transfer
         self._collect()
         Sx, _ = self.finish_exchange(hS)
+        hS = stagedS = None
         partS = torch.empty((max(mS, 1), 2), dtype=torch.int64, device=dev)
         psS = torch.empty(nparts + 1, dtype=torch.int64, device=dev)
         self._fence_torch(dev)

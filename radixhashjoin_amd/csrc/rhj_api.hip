@@ -411,9 +411,13 @@ int join_phase_on(rhj_ctx *ctx, const void *d_Rp, const u64 *d_psR, u64 nR, cons
                   u64 nS, u64 nparts, int radix_bits, u32 probe_split, void *d_out, u64 cap, u64 *out_count)
 {
     if (probe_split == 0) probe_split = 32768;
-    // a task addresses its build range with 32 bits: an unpartitioned side of >= 2^32 tuples needs a radix plan
-    if (nparts == 1 && (nR >> 32 || nS >> 32) && (nR < nS ? nR : nS) >> 32)
-        return fail(ctx, RHJ_E_INVALID, "inputs of 2^32 or more tuples need at least one partition pass");
+    // a task addresses its build range with 32 bits; k_make_tasks reports any partition whose build side is larger
+    // (counters[5], checked below) whatever the plan
+    // average build partition larger than one 4224-tuple table (an explicit plan with too few bits, or heavy
+    // duplication): the probe-stationary kernel keeps a task's probe tuples in registers, so a task is at most that many
+    const u64 nbuild = nR < nS ? nR : nS;
+    const bool big_tables = nbuild / nparts > (u64)BJ_CHUNK;
+    if (big_tables && join_big_probe_split()) probe_split = join_big_probe_split();
     const u64 max_tasks64 = nparts + (nR + nS) / probe_split + 1;
     if (max_tasks64 > 0x7fffffffull) return fail(ctx, RHJ_E_INVALID, "too many join tasks");
     const u32 max_tasks = (u32)max_tasks64;
@@ -425,10 +429,6 @@ int join_phase_on(rhj_ctx *ctx, const void *d_Rp, const u64 *d_psR, u64 nR, cons
         Span s(ctx, RHJ_K_AUX);
         HIPCHK(ctx, hipMemsetAsync(ctx->counters.p, 0, 64, ctx->stream));
     }
-    // average build partition larger than one 4224-tuple table (an explicit plan with too few bits,
-    // or heavy duplication): the one-workgroup-per-CU geometry with 8448-tuple tables re-probes half as often
-    const u64 nbuild = nR < nS ? nR : nS;
-    const bool big_tables = nbuild / nparts > (u64)BJ_CHUNK;
     {
         Span s(ctx, RHJ_K_TASKS);
         launch_make_tasks(ctx->stream, d_psR, d_psS, nparts, probe_split, (JoinTask *)ctx->tasks.p, d_ntasks, max_tasks,
@@ -440,11 +440,14 @@ int join_phase_on(rhj_ctx *ctx, const void *d_Rp, const u64 *d_psR, u64 nR, cons
                     radix_bits, d_out, d_out ? cap : 0, d_count, big_tables);
     }
     RHJCHK(check_launch(ctx, "join phase"));
-    u64 host[2] = {0, 0};
-    HIPCHK(ctx, hipMemcpyAsync(host, ctx->counters.p, 16, hipMemcpyDeviceToHost, ctx->stream));
+    u64 host[6] = {0, 0, 0, 0, 0, 0};          // count, ntasks, max |R_k|, max |S_k|, (checksum scratch), oversized build side
+    HIPCHK(ctx, hipMemcpyAsync(host, ctx->counters.p, sizeof(host), hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     *out_count = host[0];
     ctx->last.ntasks = (u32)(host[1] & 0xffffffffu);
+    if (host[5])
+        return fail(ctx, RHJ_E_INVALID, "a partition's build side has " + std::to_string(host[5]) +
+                                        " tuples (>= 2^32): use more radix bits");
     return RHJ_OK;
 }
 

@@ -15,6 +15,7 @@
 #include "rhj_internal.h"
 
 #include <cstdlib>
+#include <mutex>
 
 namespace {
 
@@ -250,32 +251,44 @@ __global__ void __launch_bounds__(1024)
 k_scan_units(const u64 *__restrict__ seg_start, const u32 *__restrict__ unit_start, u32 nseg, int bits,
              const u32 *__restrict__ unit_hist, u64 *__restrict__ unit_base, u64 *__restrict__ part_start, u64 n_total)
 {
+    // 64-bit sums throughout: a segment (a whole relation, or one pass-1 bucket of a skewed multi-billion-tuple
+    // input) may hold 2^32 tuples or more; only a UNIT's counts (<= L tuples) are 32-bit
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    u32 *part = reinterpret_cast<u32 *>(smem);          // [G][nbins] partial sums
-    __shared__ u32 wsum[16];
+    u64 *part = reinterpret_cast<u64 *>(smem);          // [G][nbins] partial sums
+    __shared__ u64 wtot[16];
     const u32 nbins = 1u << bits;
     const u32 G = 1024u / nbins;                        // >= 1
     const u32 s = blockIdx.x;
     const u32 d = threadIdx.x & (nbins - 1), g = threadIdx.x >> bits;
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const u32 us = unit_start[s], ue = unit_start[s + 1];
     const u32 nu = ue - us, per = (nu + G - 1) / G;
     const u32 gb = us + ((g * per < nu) ? g * per : nu);
     const u32 ge = us + (((g + 1) * per < nu) ? (g + 1) * per : nu);
 
-    u32 sum = 0;
+    u64 sum = 0;
     for (u32 u = gb; u < ge; u++) sum += unit_hist[(u64)u * nbins + d];
     part[g * nbins + d] = sum;
     __syncthreads();
-    u32 tot_d = 0, before = 0;
+    u64 tot_d = 0, before = 0;
     for (u32 k = 0; k < G; k++) {
-        const u32 p = part[k * nbins + d];
+        const u64 p = part[k * nbins + d];
         tot_d += p;
         if (k < g) before += p;
     }
-    u32 dummy;
-    const u32 ex = block_excl_scan<1024>(g == 0 ? tot_d : 0u, wsum, dummy);
-    // threads of group 0 hold the digit-exclusive prefix; publish through LDS for the other groups
+    // workgroup exclusive scan of the digit totals (held by the threads of group 0)
+    const u64 v = g == 0 ? tot_d : 0ull;
+    u64 inc = v;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const u64 t = __shfl_up(inc, off, 64);
+        if (lane >= off) inc += t;
+    }
+    if (lane == 63) wtot[w] = inc;
     __syncthreads();
+    u64 ex = inc - v;
+    for (int i = 0; i < w; i++) ex += wtot[i];
+    // threads of group 0 hold the digit-exclusive prefix; publish through LDS for the other groups
     if (g == 0) part[d] = ex;       // part[0][*] no longer needed: every thread has read its column
     __syncthreads();
     const u64 pstart = seg_start[s] + part[d];
@@ -720,7 +733,7 @@ k_part_max(const u64 *__restrict__ startR, const u64 *__restrict__ startS, u64 n
 
 __global__ void __launch_bounds__(1024)
 k_make_tasks(const u64 *__restrict__ startR, const u64 *__restrict__ startS, u64 nparts, u32 probe_split,
-             JoinTask *__restrict__ tasks, u32 *__restrict__ ntasks, u32 max_tasks, const u64 *__restrict__ stats,
+             JoinTask *__restrict__ tasks, u32 *__restrict__ ntasks, u32 max_tasks, u64 *__restrict__ stats,
              u32 table_tuples)
 {
     __shared__ u32 wsum[16];
@@ -744,6 +757,8 @@ k_make_tasks(const u64 *__restrict__ startR, const u64 *__restrict__ startS, u64
             if (build_S) { pbeg = r0; plen = nr; bbeg = s0; blen = ns; bis = 1; }
             else         { pbeg = s0; plen = ns; bbeg = r0; blen = nr; bis = 0; }
             nt = (u32)((plen + probe_split - 1) / probe_split);
+            // a task addresses its build range with 32 bits: report instead of truncating (host: RHJ_E_INVALID)
+            if (blen >> 32) { nt = 0; atomicMax(&stats[3], blen); }
         }
     }
     u32 tot;
@@ -759,7 +774,7 @@ k_make_tasks(const u64 *__restrict__ startR, const u64 *__restrict__ startS, u64
         t.plen = (u32)(rem < probe_split ? rem : probe_split);
         t.part = (u32)k;
         t.bbeg = bbeg;
-        t.blen = (u32)blen;              // a build side of >= 2^32 tuples in ONE partition is rejected by the host plan
+        t.blen = (u32)blen;              // < 2^32: larger build partitions were reported through stats[3] above
         t.build_is_S = bis;
         tasks[slot] = t;
     }
@@ -998,6 +1013,240 @@ k_join_bkt(const Tup *__restrict__ R, const Tup *__restrict__ S, const JoinTask 
 }
 
 // ------------------------------------------------------------------------------------------------
+// K4 (probe-stationary form): bucket join for partitions whose build side does NOT fit one LDS table
+// (explicit plans such as 8+8 bits at 10^9 tuples: 15 K-tuple partitions).  Same job as k_join_bkt
+// (JoinJob::run + Result::join_buckets, Result.cpp:43-76, + add_result/addAll), different loop order:
+//
+//   k_join_bkt:  for build chunk { build table;  for probe tile { load tile from HBM; probe } }   -> the probe
+//                side is read once PER CHUNK (measured round 1: 64 GB moved for 48 GB algorithmic, 2.0 TB/s)
+//   k_join_ps :  load the task's probe tuples ONCE into registers (EPT per thread: 1024 threads x 16 x 16 B =
+//                256 KiB, the register file is the largest memory of a CU);  for build chunk { build table; probe }
+//                -> both sides are read exactly once.
+//
+// The table of a chunk: tuples in ARRIVAL order (ds_write_b128 straight from the load registers, nothing kept in
+// VGPRs), plus a counting sort of 16-bit tuple indices by hash bucket (off[] / idx[]): 18 B per build tuple, so a
+// 7936-tuple chunk + 4096 buckets fill the 160 KiB LDS of one workgroup per CU and a 15.3 K-tuple partition is
+// two chunks.  Probe: off[h], off[h+1] -> idx[j] -> tup[idx].payload, full 64-bit equality.
+// Output: matches of the FK case (no lane with two matches in a slot) are compacted by ballot + mbcnt; pairs
+// are laid out wave-major, slot-minor, so only one total per wave goes through LDS and ONE global atomicAdd per
+// (task, chunk) reserves the pairs; consecutive lanes store consecutive 16 B pairs.
+// ------------------------------------------------------------------------------------------------
+constexpr int PS_THREADS = 1024, PS_CHUNK = 7936, PS_BUCKET_BITS = 12, PS_EPT = 16;
+constexpr u32 PS_NONE = 0xFFFFu;
+
+// slow path of one probe slot: number of build tuples of bucket [lo,hi) equal to `key` (duplicates on the build side)
+__device__ __forceinline__ u32 ps_count_bucket(const Tup *tup, const unsigned short *idx, u32 lo, u32 hi, u64 key)
+{
+    u32 c = 0;
+    for (u32 j = lo; j < hi; j++) c += (tup[idx[j]].payload == key) ? 1u : 0u;
+    return c;
+}
+
+// slow path of one probe slot: emit every match of bucket [lo,hi) starting at out[o]
+__device__ __forceinline__ void ps_emit_bucket(const Tup *tup, const unsigned short *idx, u32 lo, u32 hi, u64 key, u64 prid,
+                                            bool build_is_S, Pair *__restrict__ out, u64 o, u64 out_capacity)
+{
+    for (u32 j = lo; j < hi; j++) {
+        const Tup b = tup[idx[j]];
+        if (b.payload == key) {
+            if (o < out_capacity) {
+                Pair pr;
+                if (build_is_S) { pr.r = prid; pr.s = b.key; } else { pr.r = b.key; pr.s = prid; }
+                out[o] = pr;
+            }
+            o++;
+        }
+    }
+}
+
+template <int THREADS, int CHUNK, int BBITS, int EPT>
+__global__ void __launch_bounds__(THREADS)
+k_join_ps(const Tup *__restrict__ R, const Tup *__restrict__ S, const JoinTask *__restrict__ tasks,
+          const u32 *__restrict__ ntasks, int radix_bits, Pair *__restrict__ out, u64 out_capacity,
+          u64 *__restrict__ out_count)
+{
+    constexpr int NB = 1 << BBITS;
+    constexpr int NW = THREADS / 64;
+    constexpr int BPT = (CHUNK + THREADS - 1) / THREADS;            // build tuples per thread and chunk
+    constexpr int PER = NB / THREADS;                               // buckets per thread in the offset scan
+    static_assert(CHUNK < (int)PS_NONE && NB % THREADS == 0 && NW <= 64, "geometry");
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    Tup *tup = reinterpret_cast<Tup *>(smem);                                // CHUNK * 16, arrival order
+    u32 *off = reinterpret_cast<u32 *>(tup + CHUNK);                         // NB + 1 (+ pad to 16 B)
+    unsigned short *idx = reinterpret_cast<unsigned short *>(off + NB + 4);  // CHUNK, tuple indices grouped by bucket
+    u32 *wsum = reinterpret_cast<u32 *>(idx + ((CHUNK + 7) & ~7));           // NW scan scratch
+    u32 *wtot = wsum + NW;                                                   // NW match totals
+    u64 *gres = reinterpret_cast<u64 *>(wtot + NW);                          // 1
+
+    const u32 nt = *ntasks;
+    if (blockIdx.x >= nt) return;
+    const JoinTask task = tasks[blockIdx.x];
+    const bool build_is_S = task.build_is_S != 0;
+    const Tup *__restrict__ B = (build_is_S ? S : R) + task.bbeg;
+    const Tup *__restrict__ P = (build_is_S ? R : S) + task.pbeg;
+    const u32 nb = task.blen, np = task.plen;                                // np <= THREADS * EPT (host: probe_split)
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+
+    // the task's whole probe side: resident in registers across every build chunk.  Slot k of this thread is probe
+    // tuple k * THREADS + tid; slots k < nv are valid (one compare against a constant per use; invalid slots load
+    // tuple `tid` again, so no register is ever undefined).
+    const int nv = np > (u32)tid ? (int)((np - (u32)tid + THREADS - 1) / THREADS) : 0;
+    Tup p[EPT];
+#pragma unroll
+    for (int k = 0; k < EPT; k++) p[k] = P[k < nv ? (u32)k * THREADS + tid : (np > (u32)tid ? (u32)tid : 0u)];
+
+    for (u32 cb = 0; cb < nb; cb += CHUNK) {
+        const u32 nc = (nb - cb < (u32)CHUNK) ? nb - cb : (u32)CHUNK;
+        // Everything derived from the probe registers alone (bucket hashes, range predicates of the 16 slots) is
+        // invariant across chunks and would be hoisted out of this loop into ~50 more live registers (measured:
+        // 100 VGPRs spilled); two opaque copies keep those cheap recomputations inside the iteration.
+        int nvc = nv, rbc = radix_bits;
+        asm volatile("" : "+v"(nvc), "+s"(rbc));
+        const int nvb = nc > (u32)tid ? (int)((nc - (u32)tid + THREADS - 1) / THREADS) : 0;   // valid build slots
+        // ---- build: tuples to LDS in arrival order, counting sort of their indices by hash bucket ----
+#pragma unroll
+        for (int j = 0; j < PER; j++) off[tid * PER + j] = 0;
+        if (tid == 0) off[NB] = 0;
+        __syncthreads();
+        u32 hr[BPT];                                                         // bucket | rank << BBITS
+#pragma unroll
+        for (int k0 = 0; k0 < BPT; k0 += 4) {                                // 4 x 16 B loads in flight per lane
+            Tup bt[4];
+#pragma unroll
+            for (int k = k0; k < k0 + 4 && k < BPT; k++) bt[k - k0] = B[cb + (k < nvb ? (u32)k * THREADS + tid : 0u)];
+#pragma unroll
+            for (int k = k0; k < k0 + 4 && k < BPT; k++) {
+                const u32 i = (u32)k * THREADS + tid;
+                if (k < nvb) {
+                    tup[i] = bt[k - k0];
+                    const u32 h = bj_bucket<BBITS>(bt[k - k0].payload, rbc);
+                    hr[k] = h | (atomicAdd(&off[h], 1u) << BBITS);
+                }
+            }
+        }
+        __syncthreads();
+        {   // in-place exclusive scan of the NB bucket counts
+            u32 c[PER], loc = 0;
+#pragma unroll
+            for (int j = 0; j < PER; j++) { c[j] = off[tid * PER + j]; loc += c[j]; }
+            u32 tot;
+            u32 ex = block_excl_scan<THREADS>(loc, wsum, tot);
+#pragma unroll
+            for (int j = 0; j < PER; j++) { off[tid * PER + j] = ex; ex += c[j]; }
+            if (tid == THREADS - 1) off[NB] = ex;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < BPT; k++)
+            if (k < nvb) idx[off[hr[k] & (NB - 1)] + (hr[k] >> BBITS)] = (unsigned short)((u32)k * THREADS + tid);
+        __syncthreads();
+
+        // ---- probe, count phase: mi[k] = index of the matching build tuple (FK case), multi = slots where some
+        // lane of this wavefront has more than one match (duplicates on the build side: slow path) ----
+        u32 mi[(EPT + 1) / 2];                                               // two 16-bit indices per register
+        u32 multi = 0, wave_total = 0;
+#pragma unroll
+        for (int k = 0; k < EPT; k++) {
+            u32 lo = 0, hi = 0;
+            if (k < nvc) {
+                const u32 h = bj_bucket<BBITS>(p[k].payload, rbc);
+                lo = off[h]; hi = off[h + 1];
+            }
+            u32 c = 0, m = PS_NONE;
+            if (__ballot(hi - lo > BJ_HEAVY) == 0) {                         // short buckets everywhere: inline
+                for (u32 j = lo; j < hi; j++) {
+                    const u32 bi = idx[j];
+                    if (tup[bi].payload == p[k].payload) { c++; m = bi; }
+                }
+            } else {
+                // a few lanes facing a long bucket (duplicate-heavy build side) would serialise the workgroup:
+                // those buckets are scanned by all 64 lanes together
+                unsigned long long heavy = __ballot(hi - lo > BJ_HEAVY);
+                const bool coop = __popcll(heavy) <= BJ_HEAVY_LANES;
+                if (!coop || hi - lo <= BJ_HEAVY) {
+                    c = ps_count_bucket(tup, idx, lo, hi, p[k].payload);
+                    if (c) m = 0;                                            // marks "matched"; c > 1 or slow path re-scans
+                    if (c == 1) {                                            // recover the index for the FK write path
+                        for (u32 j = lo; j < hi; j++) { const u32 bi = idx[j]; if (tup[bi].payload == p[k].payload) m = bi; }
+                    }
+                }
+                if (coop) {
+                    while (heavy) {
+                        const int leader = __ffsll((long long)heavy) - 1;
+                        heavy &= heavy - 1;
+                        const u64 key = bj_readlane64(p[k].payload, leader);
+                        const u32 l = __builtin_amdgcn_readlane(lo, leader), hh = __builtin_amdgcn_readlane(hi, leader);
+                        u32 tot = 0, last = PS_NONE;
+                        for (u32 j = l; j < hh; j += 64) {
+                            u32 bi = 0;
+                            bool mt = false;
+                            if (j + lane < hh) { bi = idx[j + lane]; mt = tup[bi].payload == key; }
+                            const unsigned long long bal = __ballot(mt);
+                            tot += (u32)__popcll(bal);
+                            if (bal) last = __builtin_amdgcn_readlane(bi, __ffsll((long long)bal) - 1);
+                        }
+                        if (lane == leader) { c = tot; m = tot ? last : PS_NONE; }
+                    }
+                }
+            }
+            if (c == 0) m = PS_NONE;
+            if (k & 1) mi[k >> 1] |= m << 16; else mi[k >> 1] = m;
+            if (__ballot(c > 1) == 0) {
+                wave_total += (u32)__popcll(__ballot(c != 0));
+            } else {
+                multi |= 1u << k;
+                u32 r = c;
+#pragma unroll
+                for (int o2 = 32; o2 > 0; o2 >>= 1) r += __shfl_xor(r, o2, 64);
+                wave_total += r;
+            }
+        }
+        if (lane == 0) wtot[w] = wave_total;
+        __syncthreads();
+        // every wavefront scans the NW wave totals itself
+        const u32 mine = lane < NW ? wtot[lane] : 0u;
+        const u32 inc = wave_incl_scan(mine, lane);
+        const u32 chunk_total = __shfl(inc, NW - 1, 64);
+        const u32 wbase = __shfl(inc - mine, w, 64);
+        if (tid == 0 && chunk_total) *gres = atomicAdd(out_count, (u64)chunk_total);
+        __syncthreads();
+        if (chunk_total && out != nullptr && wave_total) {
+            u64 o = *gres + wbase;                                           // next output slot of this wavefront
+            const unsigned long long lt = (1ull << lane) - 1ull;
+#pragma unroll
+            for (int k = 0; k < EPT; k++) {
+                const u32 m = (k & 1) ? (mi[k >> 1] >> 16) : (mi[k >> 1] & 0xFFFFu);
+                if (!(multi & (1u << k))) {                                  // FK case: at most one match per lane
+                    const unsigned long long bal = __ballot(m != PS_NONE);
+                    if (m != PS_NONE) {
+                        const u64 dst = o + (u64)__popcll(bal & lt);
+                        if (dst < out_capacity) {
+                            const u64 brid = tup[m].key;
+                            Pair pr;
+                            if (build_is_S) { pr.r = p[k].key; pr.s = brid; }      // orderFlag, Result.cpp:64-68
+                            else            { pr.r = brid; pr.s = p[k].key; }
+                            out[dst] = pr;
+                        }
+                    }
+                    o += (u64)__popcll(bal);
+                } else {                                                     // duplicates: recount, scan, re-walk the bucket
+                    u32 lo = 0, hi = 0;
+                    if (m != PS_NONE) {
+                        const u32 h = bj_bucket<BBITS>(p[k].payload, rbc);
+                        lo = off[h]; hi = off[h + 1];
+                    }
+                    const u32 c = (m != PS_NONE) ? ps_count_bucket(tup, idx, lo, hi, p[k].payload) : 0u;
+                    const u32 ic = wave_incl_scan(c, lane);
+                    if (c) ps_emit_bucket(tup, idx, lo, hi, p[k].payload, p[k].key, build_is_S, out, o + ic - c, out_capacity);
+                    o += (u64)__shfl(ic, 63, 64);
+                }
+            }
+        }
+        __syncthreads();         // the table is rebuilt by the next chunk
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // utilities
 // ------------------------------------------------------------------------------------------------
 __device__ __forceinline__ u64 block_sum_u64(u64 v, u64 *wtot)
@@ -1092,18 +1341,40 @@ static int wc_threads_for(int bits)
 
 constexpr int BJ2_THREADS = 1024, BJ2_CHUNK = 8448, BJ2_BUCKET_BITS = 12, BJ2_EPT = 4;
 
+// oversized partitions: the probe-stationary kernel unless RHJ_JOIN_BIG=bkt asks for round 1's chunk-outer geometry
+// (kept as the measured baseline of DESIGN.md §4.2)
+bool join_big_is_ps()
+{
+    static const bool ps = !(getenv("RHJ_JOIN_BIG") && getenv("RHJ_JOIN_BIG")[0] == 'b');
+    return ps;
+}
+u32 join_big_probe_split() { return join_big_is_ps() ? (u32)(PS_THREADS * PS_EPT) : 0u; }
+u32 join_big_table_tuples() { return join_big_is_ps() ? (u32)PS_CHUNK : (u32)BJ2_CHUNK; }
+
 static size_t bj_lds_bytes(int threads, int chunk, int bbits)
 {
     return (size_t)chunk * 16 + ((size_t)(1 << bbits) + 4) * 4 + 64 * 4 + (size_t)(threads / 64) * 4 + 16;
 }
 
-static void allow_big_lds()          // per device: a process may drive several GPUs through different contexts
+// Per device (a process may drive several GPUs through different contexts) and exactly once: contexts of
+// different host threads launch concurrently (MainScheduler's 8 query threads), so the flag may only become
+// visible after every attribute has been applied -- std::call_once blocks the other callers until then.
+static int current_device_slot()
 {
-    static bool done[64] = {};
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
-    if (done[dev]) return;
-    done[dev] = true;
+    return dev;
+}
+
+static size_t ps_lds_bytes(int threads, int chunk, int bbits)
+{
+    return (size_t)chunk * 16 + ((size_t)(1 << bbits) + 4) * 4 + (size_t)((chunk + 7) & ~7) * 2 + (size_t)(threads / 64) * 8 + 16;
+}
+
+static void allow_big_lds()
+{
+    static std::once_flag done[64];
+    std::call_once(done[current_device_slot()], [] {
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_scatter_units_pipe),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)part_lds_bytes(PART_MAX_BITS));
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_scatter_wc<WC_THREADS>),
@@ -1116,6 +1387,10 @@ static void allow_big_lds()          // per device: a process may drive several 
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_join_bkt<BJ2_THREADS, BJ2_CHUNK, BJ2_BUCKET_BITS, BJ2_EPT>),
                               hipFuncAttributeMaxDynamicSharedMemorySize,
                               (int)bj_lds_bytes(BJ2_THREADS, BJ2_CHUNK, BJ2_BUCKET_BITS));
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_join_ps<PS_THREADS, PS_CHUNK, PS_BUCKET_BITS, PS_EPT>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize,
+                              (int)ps_lds_bytes(PS_THREADS, PS_CHUNK, PS_BUCKET_BITS));
+    });
 }
 
 void launch_init_single_segment(hipStream_t st, u64 n, u64 L, u64 *d_seg_start, u32 *d_unit_start)
@@ -1148,7 +1423,7 @@ void launch_scan_units(hipStream_t st, const PassGeom &g, const u64 *d_seg_start
         return;
     }
     const size_t G = 1024 / nbins;
-    hipLaunchKernelGGL(k_scan_units, dim3(g.nseg), dim3(1024), G * nbins * 4, st, d_seg_start, d_unit_start,
+    hipLaunchKernelGGL(k_scan_units, dim3(g.nseg), dim3(1024), G * nbins * 8, st, d_seg_start, d_unit_start,
                        g.nseg, g.bits, d_unit_hist, d_unit_base, d_part_start, g.n);
 }
 
@@ -1179,15 +1454,12 @@ bool fused_two_pass_ok(int b1, int b2) { return b1 >= 1 && b2 >= 1 && b1 <= WC_M
 void launch_hist2d_units(hipStream_t st, const void *d_in, u64 n, u64 L, u32 units, int b1, int b2,
                          u32 units_per_group, u32 ngroups, u32 *d_hist1, u32 *d_hist2)
 {
-    static bool once[64] = {};
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
+    static std::once_flag once[64];
     const size_t lds = ((size_t)1 << (b1 + b2)) * 2 + ((size_t)4 << b1);
-    if (!once[dev]) {
-        once[dev] = true;
+    std::call_once(once[current_device_slot()], [] {
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_hist2d_units),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)(((size_t)1 << 16) * 2 + ((size_t)4 << WC_MAX_BITS)));
-    }
+    });
     if (units == 0) return;
     hipLaunchKernelGGL(k_hist2d_units, dim3(units), dim3(H2_THREADS), lds, st, (const Tup *)d_in, n, L, b1, b2,
                        units_per_group, ngroups, d_hist1, d_hist2);
@@ -1233,8 +1505,8 @@ void launch_make_tasks(hipStream_t st, const u64 *d_startR, const u64 *d_startS,
     if (g > 1024) g = 1024;
     hipLaunchKernelGGL(k_part_max, dim3((unsigned)g), dim3(256), 0, st, d_startR, d_startS, nparts, d_stats);   // d_stats zeroed by the caller
     hipLaunchKernelGGL(k_make_tasks, dim3((unsigned)((nparts + 1023) / 1024)), dim3(1024), 0, st, d_startR, d_startS,
-                       nparts, probe_split, d_tasks, d_ntasks, max_tasks, (const u64 *)d_stats,
-                       (u32)(big_tables ? BJ2_CHUNK : BJ_CHUNK));
+                       nparts, probe_split, d_tasks, d_ntasks, max_tasks, d_stats,
+                       big_tables ? join_big_table_tuples() : (u32)BJ_CHUNK);
 }
 
 void launch_join(hipStream_t st, const void *d_R, const u64 *d_startR, const void *d_S, const u64 *d_startS,
@@ -1246,6 +1518,12 @@ void launch_join(hipStream_t st, const void *d_R, const u64 *d_startR, const voi
     if (!big_tables) {
         hipLaunchKernelGGL((k_join_bkt<BJ_THREADS, BJ_CHUNK, BJ_BUCKET_BITS, BJ_EPT>), dim3(grid), dim3(BJ_THREADS),
                            bj_lds_bytes(BJ_THREADS, BJ_CHUNK, BJ_BUCKET_BITS), st, (const Tup *)d_R, (const Tup *)d_S,
+                           d_tasks, d_ntasks, radix_bits, (Pair *)d_out, out_capacity, d_out_count);
+        return;
+    }
+    if (join_big_is_ps()) {
+        hipLaunchKernelGGL((k_join_ps<PS_THREADS, PS_CHUNK, PS_BUCKET_BITS, PS_EPT>), dim3(grid), dim3(PS_THREADS),
+                           ps_lds_bytes(PS_THREADS, PS_CHUNK, PS_BUCKET_BITS), st, (const Tup *)d_R, (const Tup *)d_S,
                            d_tasks, d_ntasks, radix_bits, (Pair *)d_out, out_capacity, d_out_count);
         return;
     }

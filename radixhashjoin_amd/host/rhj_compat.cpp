@@ -9,8 +9,8 @@
 #include <queue>
 #include <thread>
 
-// n host threads, each owning a private JobScheduler (= a private rhj_ctx): the reference's
-// mainThreadWork (MainScheduler.cpp:6-14) with std::thread instead of pthreads.
+// job queue + host threads of a scheduler started with init(n, start_routine): the reference's
+// queue / mutex / condvars / pthread_t[] (JobScheduler.h:88-96) with std::thread instead of pthreads.
 struct WorkerPool {
     std::mutex mu;
     std::condition_variable cv_work, cv_idle;
@@ -64,40 +64,41 @@ bool JobScheduler::init(size_t n)
     return true;
 }
 
-bool JobScheduler::start_query_threads(size_t n)
+// JobScheduler.cpp:67-82.  The start routine receives `this`, exactly like the pthread start routines of the
+// reference (jobThreadWork / mainThreadWork); it is expected to end up in threadWork().
+bool JobScheduler::init(size_t n, void *start_routine(void *))
 {
     num_of_threads = n;
     pool_ = new WorkerPool();
-    for (size_t i = 0; i < n; i++) {
-        pool_->threads.emplace_back([this]() {
-            JobScheduler mine;                        // private scheduler = private GPU context
-            mine.init(NUM_OF_THREADS);
-            WorkerPool &p = *pool_;
-            for (;;) {
-                Job *job = nullptr;
-                {
-                    std::unique_lock<std::mutex> lk(p.mu);
-                    p.cv_work.wait(lk, [&] { return p.done || !p.q.empty(); });
-                    if (p.q.empty()) break;           // done and drained
-                    job = p.q.front();
-                    p.q.pop();
-                    p.busy++;
-                }
-                job->gpu = mine.context();
-                job->init(&mine);                     // QueryJob::init receives its private JobScheduler
-                job->run();
-                delete job;
-                {
-                    std::lock_guard<std::mutex> lk(p.mu);
-                    p.busy--;
-                    if (p.q.empty() && p.busy == 0) p.cv_idle.notify_all();
-                }
-            }
-            mine.stop();
-            mine.destroy();
-        });
-    }
+    for (size_t i = 0; i < n; i++) pool_->threads.emplace_back([this, start_routine]() { (void)start_routine(this); });
     return true;
+}
+
+// JobScheduler.cpp:22-64: run queued jobs until stop() has been called and the queue is drained.
+void JobScheduler::threadWork(void *arg)
+{
+    if (!pool_) return;                               // no queue: init(n) schedulers run jobs on the caller
+    WorkerPool &p = *pool_;
+    for (;;) {
+        Job *job = nullptr;
+        {
+            std::unique_lock<std::mutex> lk(p.mu);
+            p.cv_work.wait(lk, [&] { return p.done || !p.q.empty(); });
+            if (p.q.empty()) return;                  // done and drained
+            job = p.q.front();
+            p.q.pop();
+            p.busy++;
+        }
+        job->gpu = ctx_;
+        job->init(arg);                               // QueryJob::init receives the query thread's private JobScheduler
+        job->run();
+        delete job;                                   // JobScheduler.cpp:53
+        {
+            std::lock_guard<std::mutex> lk(p.mu);
+            p.busy--;
+            if (p.q.empty() && p.busy == 0) p.cv_idle.notify_all();
+        }
+    }
 }
 
 int JobScheduler::schedule(Job *job)

@@ -4,7 +4,9 @@
  *     structs.h (tuple / relation / relation_info), Result.h (key_tuple / bucket_info / Result),
  *     JobScheduler.h (Job / HistogramJob / PartitionJob / JoinJob / JobScheduler)
  * compiles against this header unchanged: same type names, member names, argument order and
- * meaning.  What differs is WHERE the work runs:
+ * meaning (tests/test_integration_build.py compiles the reference's own Query.cpp, intermediate.cpp,
+ * MainScheduler.cpp and join.cpp against it).  `Job` carries one extra public member, `gpu`, which the
+ * reference's callers never touch.  What differs is WHERE the work runs:
  *
  *   reference (CPU, pthreads)                              here (MI355X)
  *   ----------------------------------------------------   --------------------------------------------
@@ -55,13 +57,17 @@ class JobScheduler {                          /* JobScheduler.h:87-124 */
     rhj_ctx *ctx_ = nullptr;
     size_t num_of_threads = 0;
     void *job_arg_ = nullptr;                 /* what Job::init receives (the reference passes threadWork's argument) */
-protected:
-    WorkerPool *pool_ = nullptr;              /* only MainScheduler: n host threads, each with a private JobScheduler */
-    bool start_query_threads(size_t n);       /* MainScheduler.cpp:6-18 */
+    WorkerPool *pool_ = nullptr;              /* queue + host threads; only after init(n, start_routine) */
 public:
     JobScheduler() = default;
     virtual ~JobScheduler() = default;
 
+    /* JobScheduler.cpp:22-64: the worker loop.  Takes jobs off this scheduler's queue until stop(); every job gets
+       job->init(arg) before run() and is deleted afterwards.  Only meaningful after init(n, start_routine). */
+    void threadWork(void *arg);
+    /* JobScheduler.cpp:67-82: n host threads, each running start_routine(this) (which is expected to call
+       threadWork, as mainThreadWork does, MainScheduler.cpp:6-14).  Opens no GPU context of its own. */
+    bool init(size_t num_of_threads, void *start_routine(void *));
     virtual bool init(size_t num_of_threads); /* JobScheduler.cpp:84-86: here: rhj_init on $RHJ_DEVICE (default 0) */
     bool destroy();                           /* JobScheduler.cpp:89-97  */
     void barrier();                           /* JobScheduler.cpp:103-122: all scheduled work has completed */

@@ -364,4 +364,16 @@ QueryJob::QueryJob(Query &q, vector<relList> &rels) : query(q), relations(rels),
 void QueryJob::init(void *arg) { js = (JobScheduler *)arg; }
 int QueryJob::run() { query.execute(*js, relations); return 0; }
 
-bool MainScheduler::init(size_t n) { return start_query_threads(n); }
+// start routine of a query thread (MainScheduler.cpp:6-14): a private JobScheduler = a private GPU context
+static void *mainThreadWork(void *arg)
+{
+    MainScheduler *ms = (MainScheduler *)arg;
+    JobScheduler mine;
+    mine.init(NUM_OF_THREADS);
+    ms->threadWork(&mine);
+    mine.stop();
+    mine.destroy();
+    return nullptr;
+}
+
+bool MainScheduler::init(size_t n) { return JobScheduler::init(n, mainThreadWork); }

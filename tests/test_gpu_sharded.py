@@ -1,0 +1,93 @@
+"""GPU suite: the multi-GPU driver (radixhashjoin_amd/sharded.py) with the REAL engine.
+
+A gpurun box has one MI355X, so world_size 2 (and 3: class ranges need no power of two) run as ranks that share
+cuda:0, with gloo moving the exchange through the host (RHJ_BENCH_BACKEND=gloo does the same for bench.py).  Everything
+except the transport is what an 8-GPU job runs: rhj_partition_at class split, count matrix, uneven
+all_to_all_single, rhj_partition of what arrived, rhj_bucket_join, sharded result.  The union of the ranks' pair sets
+must equal the CPU oracle's join of the global relations."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch.multiprocessing as mp
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def worker(rank, world, port, n_per_rank, D, zipf, opts, q):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    import torch
+    import torch.distributed as dist
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import radixhashjoin_amd as rhj
+    from radixhashjoin_amd.binding import GEN_R, GEN_S_UNIFORM, GEN_S_ZIPF
+    from radixhashjoin_amd.sharded import ShardedJoin
+    from oracle.pyoracle import Oracle, TUPLE
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_device(dev)
+    eng = rhj.Engine(0)                                   # fails loudly without the HIP library / GPU
+    nglob = n_per_rank * world
+    R = torch.empty((n_per_rank, 2), dtype=torch.int64, device=dev)
+    S = torch.empty((n_per_rank, 2), dtype=torch.int64, device=dev)
+    eng.generate(GEN_R, R, n_per_rank, row0=rank * n_per_rank, D=D)
+    eng.generate(GEN_S_ZIPF if zipf else GEN_S_UNIFORM, S, n_per_rank, row0=rank * n_per_rank, D=D, seed=42, theta_milli=zipf or 0)
+    eng.sync()
+    sj = ShardedJoin(eng, dist.group.WORLD, local_opts=rhj.Opts(*opts) if opts else None)
+    cnt, out = sj.join(R, n_per_rank, S, n_per_rank)
+    torch.cuda.synchronize()
+    pairs = out[:cnt].cpu().numpy().view(np.uint64)
+    shards = [None] * world
+    dist.all_gather_object(shards, (R.cpu().numpy().view(np.uint64), S.cpu().numpy().view(np.uint64), pairs,
+                                    sj.stats["recv_R"] + sj.stats["recv_S"]))
+    if rank == 0:
+        o = Oracle()
+        def tup(parts):
+            a = np.concatenate(parts)
+            t = np.empty(len(a), dtype=TUPLE)
+            t["key"], t["payload"] = a[:, 0], a[:, 1]
+            return t
+        Rg, Sg = tup([s[0] for s in shards]), tup([s[1] for s in shards])
+        assert np.array_equal(Rg["key"], np.arange(nglob, dtype=np.uint64))            # rowIDs stay global
+        exp = o.join(Rg, Sg)
+        allp = np.concatenate([s[2] for s in shards])
+        a = allp[np.lexsort((allp[:, 1], allp[:, 0]))]
+        e = np.stack([exp["keyR"], exp["keyS"]], axis=1)
+        e = e[np.lexsort((e[:, 1], e[:, 0]))]
+        recv = [s[3] for s in shards]
+        q.put((len(allp), len(exp), bool(np.array_equal(a, e)), max(recv) / (sum(recv) / world)))
+    dist.barrier()
+    eng.close()
+    dist.destroy_process_group()
+
+
+def free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+@pytest.mark.parametrize("world,n_per_rank,D,zipf,opts", [(2, 1_500_000, 3_000_000, 0, None),       # PK/FK, automatic local plan
+                                                          (2, 400_000, 100_000, 0, (2, 4, 4)),      # duplicates, forced two-pass plan
+                                                          (3, 300_000, 900_000, 1250, None)])       # skew, 3 ranks
+def test_sharded_join_real_engine(world, n_per_rank, D, zipf, opts):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = free_port()
+    procs = [ctx.Process(target=worker, args=(r, world, port, n_per_rank, D, zipf, opts, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got, exp, same, imbalance = q.get(timeout=600)
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    assert got == exp and same
+    if zipf:
+        assert imbalance <= 1.3, imbalance

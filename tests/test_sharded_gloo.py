@@ -68,7 +68,18 @@ class OracleEngine:
         return len(p)
 
 
-def worker(rank, world, port, n_per_rank, dup, staged, q):
+def zipf_payloads(o, n, D, theta, seed):
+    """Zipf(theta) ranks over [1, D] by inverse CDF of the continuous approximation, mapped through mix() like
+    the device generator (rhj_generate_dev kind 2); numpy only, the same on every rank"""
+    rng = np.random.default_rng(seed)
+    e = 1.0 - theta
+    u = rng.random(n)
+    r = np.clip(np.power(1.0 + u * (np.power(D + 1.0, e) - 1.0), 1.0 / e).astype(np.int64), 1, D)
+    lut = np.array([o.mix(int(k)) for k in range(D + 1)], dtype=np.uint64)
+    return lut[r]
+
+
+def worker(rank, world, port, n_per_rank, dup, staged, q, zipf=None, balance=True):
     sys.path.insert(0, ROOT)
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
@@ -79,6 +90,8 @@ def worker(rank, world, port, n_per_rank, dup, staged, q):
     nglob = n_per_rank * world
     D = max(nglob // dup, 1)
     Rg, Sg = o.gen_R(nglob, D), o.gen_S_counter(nglob, D, 42)       # global relations, rows range-sharded
+    if zipf is not None:
+        Sg["payload"] = zipf_payloads(o, nglob, D, zipf, 7)         # skewed foreign key, same array on every rank
     lo, hi = rank * n_per_rank, (rank + 1) * n_per_rank
 
     def shard(t):
@@ -86,15 +99,16 @@ def worker(rank, world, port, n_per_rank, dup, staged, q):
         a[:, 0], a[:, 1] = t["key"][lo:hi], t["payload"][lo:hi]
         return torch.from_numpy(a.view(np.int64))
 
-    sj = ShardedJoin(OracleEngine(), dist.group.WORLD)
+    sj = ShardedJoin(OracleEngine(), dist.group.WORLD, balance=balance)
     sj.staged_local_join = staged
     cnt, out = sj.join(shard(Rg), n_per_rank, shard(Sg), n_per_rank)
     pairs = out.numpy()[:cnt].view(np.uint64)
     # every pair this rank produced belongs to its owner class
-    own = (Rg["payload"][pairs[:, 0].astype(np.int64)] >> np.uint64(sj.owner_shift)) & np.uint64(world - 1)
-    assert np.all(own == rank)
-    gathered = [None] * world
+    assert np.all(sj.owner_of(Rg["payload"][pairs[:, 0].astype(np.int64)]) == rank)
+    gathered, received = [None] * world, [None] * world
     dist.all_gather_object(gathered, pairs)
+    dist.all_gather_object(received, sj.stats["recv_R"] + sj.stats["recv_S"])
+    sj.stats["received_per_rank"] = received
     if rank == 0:
         allp = np.concatenate(gathered)
         exp = o.join(Rg, Sg)
@@ -114,13 +128,11 @@ def free_port():
     return p
 
 
-@pytest.mark.parametrize("world,n_per_rank,dup,staged", [(2, 20_000, 1, True), (2, 5_000, 4, False), (4, 6_000, 2, True),
-                                                         (2, 1_000, 1, True)])
-def test_sharded_join_equals_global_join(world, n_per_rank, dup, staged):
+def run_world(world, *args):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = free_port()
-    procs = [ctx.Process(target=worker, args=(r, world, port, n_per_rank, dup, staged, q)) for r in range(world)]
+    procs = [ctx.Process(target=worker, args=(r, world, port) + args[:3] + (q,) + args[3:]) for r in range(world)]
     for p in procs:
         p.start()
     got, exp, same, stats = q.get(timeout=180)
@@ -128,3 +140,26 @@ def test_sharded_join_equals_global_join(world, n_per_rank, dup, staged):
         p.join(timeout=60)
         assert p.exitcode == 0
     assert got == exp and same
+    return stats
+
+
+@pytest.mark.parametrize("world,n_per_rank,dup,staged", [(2, 20_000, 1, True), (2, 5_000, 4, False), (4, 6_000, 2, True),
+                                                         (2, 1_000, 1, True), (3, 4_000, 1, True)])
+def test_sharded_join_equals_global_join(world, n_per_rank, dup, staged):
+    run_world(world, n_per_rank, dup, staged)
+
+
+def test_skewed_join_values_are_balanced_over_ranks():
+    """Zipf(1.25) foreign key: the hottest join value alone is ~a fifth of S.  Equal-width class ranges (a static
+    radix map) overload the rank that owns it; ranges cut from the all-gathered class histogram keep every rank
+    within 1.3x of the mean, with the same pair set."""
+    world, n = 4, 12_000
+
+    def imbalance(stats):
+        r = stats["received_per_rank"]
+        return max(r) / (sum(r) / len(r))
+
+    static = imbalance(run_world(world, n, 1, True, 1.25, False))
+    balanced = imbalance(run_world(world, n, 1, True, 1.25, True))
+    assert static > 1.3, static                    # the input really is skewed enough to matter
+    assert balanced <= 1.3, balanced

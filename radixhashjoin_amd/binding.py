@@ -56,6 +56,7 @@ SYMBOLS = {
     "rhj_last_error": (C.c_char_p, [_vp]),
     "rhj_set_stream": (C.c_int, [_vp, _vp]),
     "rhj_set_profiling": (C.c_int, [_vp, C.c_int]),
+    "rhj_set_option": (C.c_int, [_vp, C.c_char_p, C.c_int64]),
     "rhj_get_timings": (C.c_int, [_vp, _P(Timings)]),
     "rhj_sync": (C.c_int, [_vp]),
     "rhj_reserve": (C.c_int, [_vp, _u64, _u64, _P(Opts)]),
@@ -193,6 +194,10 @@ class Engine:
     # ---- context ------------------------------------------------------------------------------
     def set_stream(self, raw_stream):
         self._chk(self.lib.rhj_set_stream(self.ctx, raw_stream))
+
+    def set_option(self, name, value):
+        """tuning / test knobs of include/rhj.h (results never depend on them)"""
+        self._chk(self.lib.rhj_set_option(self.ctx, name.encode(), int(value)))
 
     def set_profiling(self, on=True):
         self._chk(self.lib.rhj_set_profiling(self.ctx, 1 if on else 0))

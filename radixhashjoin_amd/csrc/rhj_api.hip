@@ -63,6 +63,9 @@ struct rhj_ctx {
     u64 cur_nparts = 0, cur_nR = 0, cur_nS = 0;
     int cur_radix_bits = 0;
     u32 cur_probe_split = 0;
+    // tuning / test knobs (rhj_set_option)
+    int opt_big_tables = -1;           // -1: by average build partition size, 0: never, 1: always use an oversized-partition kernel
+    int opt_big_kernel = -1;           // -1: automatic, JK_BKT_BIG: never the compact-table kernel
 };
 
 namespace {
@@ -413,11 +416,14 @@ int join_phase_on(rhj_ctx *ctx, const void *d_Rp, const u64 *d_psR, u64 nR, cons
     if (probe_split == 0) probe_split = 32768;
     // a task addresses its build range with 32 bits; k_make_tasks reports any partition whose build side is larger
     // (counters[5], checked below) whatever the plan
-    // average build partition larger than one 4224-tuple table (an explicit plan with too few bits, or heavy
-    // duplication): the probe-stationary kernel keeps a task's probe tuples in registers, so a task is at most that many
+    // Average build partition larger than one 4224-tuple table (an explicit plan with too few bits, or more than 2^30
+    // tuples): the compact-table kernel when the plan removed enough payload bits for 48-bit keys, else 8448-tuple
+    // chunks.  The compact-table kernel keeps a task's probe rowIDs in registers, so a task is at most that many tuples.
     const u64 nbuild = nR < nS ? nR : nS;
-    const bool big_tables = nbuild / nparts > (u64)BJ_CHUNK;
-    if (big_tables && join_big_probe_split()) probe_split = join_big_probe_split();
+    int kind = JK_BKT;
+    if (ctx->opt_big_tables == 1 || (ctx->opt_big_tables < 0 && nbuild / nparts > (u64)BJ_CHUNK))
+        kind = (radix_bits >= join_ct_min_radix_bits() && ctx->opt_big_kernel != JK_BKT_BIG) ? JK_CT : JK_BKT_BIG;
+    if (join_probe_split(kind) && probe_split > join_probe_split(kind)) probe_split = join_probe_split(kind);
     const u64 max_tasks64 = nparts + (nR + nS) / probe_split + 1;
     if (max_tasks64 > 0x7fffffffull) return fail(ctx, RHJ_E_INVALID, "too many join tasks");
     const u32 max_tasks = (u32)max_tasks64;
@@ -432,12 +438,12 @@ int join_phase_on(rhj_ctx *ctx, const void *d_Rp, const u64 *d_psR, u64 nR, cons
     {
         Span s(ctx, RHJ_K_TASKS);
         launch_make_tasks(ctx->stream, d_psR, d_psS, nparts, probe_split, (JoinTask *)ctx->tasks.p, d_ntasks, max_tasks,
-                          d_count + 2, big_tables);                 // counters[2..3]: largest partition of R, S
+                          d_count + 2, kind);                       // counters[2..3]: largest partition of R, S
     }
     {
         Span s(ctx, RHJ_K_JOIN);
         launch_join(ctx->stream, d_Rp, d_psR, d_Sp, d_psS, (const JoinTask *)ctx->tasks.p, d_ntasks, max_tasks,
-                    radix_bits, d_out, d_out ? cap : 0, d_count, big_tables);
+                    radix_bits, d_out, d_out ? cap : 0, d_count, kind);
     }
     RHJCHK(check_launch(ctx, "join phase"));
     u64 host[6] = {0, 0, 0, 0, 0, 0};          // count, ntasks, max |R_k|, max |S_k|, (checksum scratch), oversized build side
@@ -561,6 +567,15 @@ int rhj_set_stream(rhj_ctx *ctx, void *hip_stream)
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     ctx->stream = hip_stream ? (hipStream_t)hip_stream : ctx->own_stream;
     return RHJ_OK;
+}
+
+int rhj_set_option(rhj_ctx *ctx, const char *name, int64_t value)
+{
+    if (!ctx || !name) return fail(ctx, RHJ_E_INVALID, "rhj_set_option: null argument");
+    const std::string n(name);
+    if (n == "join.big_tables" && value >= -1 && value <= 1) { ctx->opt_big_tables = (int)value; return RHJ_OK; }
+    if (n == "join.big_kernel" && (value == -1 || value == JK_BKT_BIG || value == JK_CT)) { ctx->opt_big_kernel = (int)value; return RHJ_OK; }
+    return fail(ctx, RHJ_E_INVALID, "rhj_set_option: unknown option or value: " + n);
 }
 
 int rhj_set_profiling(rhj_ctx *ctx, int enabled)

@@ -55,17 +55,21 @@ void launch_scatter_units(hipStream_t st, const void *d_in, void *d_out, const P
 void launch_diff_hist(hipStream_t st, const u64 *d_start, u64 nbins, u64 *d_hist);
 void launch_prefix(hipStream_t st, const u64 *d_hist, u64 nbins, u64 *d_start);
 void launch_make_tasks(hipStream_t st, const u64 *d_startR, const u64 *d_startS, u64 nparts, u32 probe_split,
-                       JoinTask *d_tasks, u32 *d_ntasks, u32 max_tasks, u64 *d_stats, bool big_tables);
+                       JoinTask *d_tasks, u32 *d_ntasks, u32 max_tasks, u64 *d_stats, int kind);
 void launch_join(hipStream_t st, const void *d_R, const u64 *d_startR, const void *d_S, const u64 *d_startS,
                  const JoinTask *d_tasks, const u32 *d_ntasks, u32 grid, int radix_bits,
-                 void *d_out, u64 out_capacity, u64 *d_out_count, bool big_tables);
+                 void *d_out, u64 out_capacity, u64 *d_out_count, int kind);
 void launch_checksum(hipStream_t st, const void *d_pairs, u64 n, u64 *d_sum);
 void launch_generate(hipStream_t st, int kind, void *d_out, u64 n, u64 row0, u64 D, u64 seed, double theta);
 void launch_expected_pkfk(hipStream_t st, const void *d_S, u64 n, u64 *d_sum);
 bool fused_two_pass_ok(int b1, int b2);
-bool join_big_is_ps();
-u32 join_big_probe_split();          // probe tuples per task the oversized-partition kernel holds in registers (0: no limit)
-u32 join_big_table_tuples();
+// bucket-join kernels: JK_BKT partitions that fit one 4224-tuple table (two workgroups per CU); JK_BKT_BIG 8448-tuple
+// chunks, probe side re-read per chunk (any radix plan); JK_CT compact 8-byte entries, both sides read once
+// (plans that remove >= 16 payload bits)
+enum JoinKernel { JK_BKT = 0, JK_BKT_BIG = 1, JK_CT = 2 };
+u32 join_probe_split(int kind);      // probe tuples per task the kernel holds at most (0: no limit of its own)
+u32 join_table_tuples(int kind);     // build tuples per LDS table
+int join_ct_min_radix_bits();
 void launch_hist2d_units(hipStream_t st, const void *d_in, u64 n, u64 L, u32 units, int b1, int b2,
                          u32 units_per_group, u32 ngroups, u32 *d_hist1, u32 *d_hist2);
 void launch_make_group_ranges(hipStream_t st, const u64 *d_unit_base1, u32 nb1, u32 units_per_group, u32 ngroups, u64 n,

@@ -14,8 +14,10 @@
 // No MFMA anywhere: the path is 64-bit integer hashing and data movement, bounded by HBM.
 #include "rhj_internal.h"
 
+#include <cstdio>
 #include <cstdlib>
 #include <mutex>
+#include <vector>
 
 namespace {
 
@@ -1013,68 +1015,75 @@ k_join_bkt(const Tup *__restrict__ R, const Tup *__restrict__ S, const JoinTask 
 }
 
 // ------------------------------------------------------------------------------------------------
-// K4 (probe-stationary form): bucket join for partitions whose build side does NOT fit one LDS table
-// (explicit plans such as 8+8 bits at 10^9 tuples: 15 K-tuple partitions).  Same job as k_join_bkt
-// (JoinJob::run + Result::join_buckets, Result.cpp:43-76, + add_result/addAll), different loop order:
+// K4 (compact-table form): bucket join for partitions whose build side does not fit a 16 B/tuple LDS table but
+// whose radix plan has removed >= 16 payload bits (BASELINE config 3: 8+8 bits at 10^9 tuples, 15.3 K-tuple
+// partitions).  Same job as k_join_bkt (JoinJob::run + Result::join_buckets, Result.cpp:43-76, + add_result /
+// addAll), organised so that BOTH sides are read from HBM exactly once and every tuple is inserted / probed once:
 //
-//   k_join_bkt:  for build chunk { build table;  for probe tile { load tile from HBM; probe } }   -> the probe
-//                side is read once PER CHUNK (measured round 1: 64 GB moved for 48 GB algorithmic, 2.0 TB/s)
-//   k_join_ps :  load the task's probe tuples ONCE into registers (EPT per thread: 1024 threads x 16 x 16 B =
-//                256 KiB, the register file is the largest memory of a CU);  for build chunk { build table; probe }
-//                -> both sides are read exactly once.
-//
-// The table of a chunk: tuples in ARRIVAL order (ds_write_b128 straight from the load registers, nothing kept in
-// VGPRs), plus a counting sort of 16-bit tuple indices by hash bucket (off[] / idx[]): 18 B per build tuple, so a
-// 7936-tuple chunk + 4096 buckets fill the 160 KiB LDS of one workgroup per CU and a 15.3 K-tuple partition is
-// two chunks.  Probe: off[h], off[h+1] -> idx[j] -> tup[idx].payload, full 64-bit equality.
-// Output: matches of the FK case (no lane with two matches in a slot) are compacted by ballot + mbcnt; pairs
-// are laid out wave-major, slot-minor, so only one total per wave goes through LDS and ONE global atomicAdd per
-// (task, chunk) reserves the pairs; consecutive lanes store consecutive 16 B pairs.
+//   * inside a partition all payloads share their low radix_bits bits, so (payload >> radix_bits) < 2^48 decides
+//     equality: a table entry is 8 bytes, {48-bit key | 16-bit arrival index of the build tuple}.  17920 entries +
+//     8192 bucket offsets fill the 160 KiB LDS of one workgroup per CU: the whole 15.3 K-tuple build side is ONE
+//     table (k_join_bkt needs two 8448-tuple chunks and re-reads the probe side per chunk: 64 GB moved for 48 GB
+//     algorithmic, 2.0 TB/s, round 1).
+//   * the probe side streams through a 3-tile register ring; a probe tuple leaves in registers its rowID and its
+//     matches as {first table position of its bucket, bit mask of the matching entries} (512 threads x 256 VGPRs: the
+//     register file, 512 KiB per CU, is the largest memory there is: it holds a whole 16 K-tuple probe task).
+//     Several matches per probe tuple (duplicates on the build side: every second partition of a PK/FK join builds on
+//     the foreign-key side, JobScheduler.cpp:187) cost nothing extra.
+//   * when every probe is done the keys are dead: the build rowIDs (re-fetched from the partition, see below) are
+//     written over the table IN TABLE ORDER (each thread kept the 16-bit position of the entries it placed), and the
+//     pairs (rowR,rowS) are completed from LDS.  One global atomicAdd per task reserves the output; matches are compacted
+//     per wavefront slot by ballot + mbcnt; consecutive lanes store consecutive 16 B pairs.
+//   * buckets of more than 16 entries (a join value repeated many times on the build side, e.g. skew) do not fit the
+//     mask: such (wavefront, tile)s go through a generic loop that re-reads the slot's probe tuple, scans long buckets
+//     with all 64 lanes, reserves its own output range and fetches build rowIDs from the partition in L2/HBM by the
+//     16-bit arrival index every entry carries -- correct for any input, off the fast path's registers.
+// Bucket counts are 16-bit halves of 32-bit LDS words (ds_add_rtn on the word; a half cannot carry: <= 17920 per
+// workgroup), so 8192 buckets cost 16 KiB and the average bucket holds 1.9 entries.
 // ------------------------------------------------------------------------------------------------
-constexpr int PS_THREADS = 1024, PS_CHUNK = 7936, PS_BUCKET_BITS = 12, PS_EPT = 16;
-constexpr u32 PS_NONE = 0xFFFFu;
+constexpr int CT_THREADS = 512, CT_CHUNK = 17920, CT_BUCKET_BITS = 13, CT_EPT = 32, CT_PT = 4, CT_DEPTH = 3;
+constexpr u32 CT_NONE = 0xFFFFu;
+constexpr int CT_MIN_RADIX_BITS = 16;       // keys must fit 48 bits
+constexpr u32 CT_MASK_BITS = 16;            // a probe records its matches as a bit mask over a bucket of at most this many entries
 
-// slow path of one probe slot: number of build tuples of bucket [lo,hi) equal to `key` (duplicates on the build side)
-__device__ __forceinline__ u32 ps_count_bucket(const Tup *tup, const unsigned short *idx, u32 lo, u32 hi, u64 key)
+// 32-bit Fibonacci hash of the folded key: one quarter-rate multiply instead of the four of a 64-bit product (the probe
+// phase is issue-bound at two wavefronts per SIMD)
+template <int BBITS>
+__device__ __forceinline__ u32 ct_bucket(u64 key)
 {
-    u32 c = 0;
-    for (u32 j = lo; j < hi; j++) c += (tup[idx[j]].payload == key) ? 1u : 0u;
-    return c;
+    return (((u32)key ^ (u32)(key >> 32)) * 0x9E3779B1u) >> (32 - BBITS);
 }
 
-// slow path of one probe slot: emit every match of bucket [lo,hi) starting at out[o]
-__device__ __forceinline__ void ps_emit_bucket(const Tup *tup, const unsigned short *idx, u32 lo, u32 hi, u64 key, u64 prid,
-                                            bool build_is_S, Pair *__restrict__ out, u64 o, u64 out_capacity)
-{
-    for (u32 j = lo; j < hi; j++) {
-        const Tup b = tup[idx[j]];
-        if (b.payload == key) {
-            if (o < out_capacity) {
-                Pair pr;
-                if (build_is_S) { pr.r = prid; pr.s = b.key; } else { pr.r = b.key; pr.s = prid; }
-                out[o] = pr;
-            }
-            o++;
-        }
-    }
-}
+// STAMPS: tuning aid (RHJ_CT_STAMPS=1): thread 0 of the first workgroups records s_memrealtime (100 MHz) at phase
+// boundaries into `stamps` (CT_NSTAMP words per workgroup); never set in production launches.
+constexpr int CT_NSTAMP = 16;
 
-template <int THREADS, int CHUNK, int BBITS, int EPT>
+template <int THREADS, int CHUNK, int BBITS, int EPT, bool STAMPS>
 __global__ void __launch_bounds__(THREADS)
-k_join_ps(const Tup *__restrict__ R, const Tup *__restrict__ S, const JoinTask *__restrict__ tasks,
+k_join_ct(const Tup *__restrict__ R, const Tup *__restrict__ S, const JoinTask *__restrict__ tasks,
           const u32 *__restrict__ ntasks, int radix_bits, Pair *__restrict__ out, u64 out_capacity,
-          u64 *__restrict__ out_count)
+          u64 *__restrict__ out_count, u64 *__restrict__ stamps, u32 nstamp_wgs)
 {
+    int stamp_i = 0;
+    auto stamp = [&]() {
+        if (STAMPS && threadIdx.x == 0 && blockIdx.x < nstamp_wgs && stamp_i < CT_NSTAMP)
+            stamps[(u64)blockIdx.x * CT_NSTAMP + stamp_i++] = __builtin_amdgcn_s_memrealtime();
+    };
+    stamp();                                                                 // 0: start
     constexpr int NB = 1 << BBITS;
     constexpr int NW = THREADS / 64;
-    constexpr int BPT = (CHUNK + THREADS - 1) / THREADS;            // build tuples per thread and chunk
-    constexpr int PER = NB / THREADS;                               // buckets per thread in the offset scan
-    static_assert(CHUNK < (int)PS_NONE && NB % THREADS == 0 && NW <= 64, "geometry");
+    constexpr int BPT = (CHUNK + THREADS - 1) / THREADS;            // build tuples per thread
+    constexpr int BB = 7;                                           // build loads in flight per lane
+    constexpr int WPT = NB / 2 / THREADS;                           // packed counter words per thread in the scan
+    constexpr int PT = CT_PT, NT = EPT / PT, DEPTH = CT_DEPTH;      // probe tile: PT slots; ring of DEPTH tiles
+    static_assert(EPT % PT == 0 && EPT <= 32 && NB % (2 * THREADS) == 0 && CHUNK < (int)CT_NONE && BPT % BB == 0 && NW <= 64,
+                  "geometry");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    Tup *tup = reinterpret_cast<Tup *>(smem);                                // CHUNK * 16, arrival order
-    u32 *off = reinterpret_cast<u32 *>(tup + CHUNK);                         // NB + 1 (+ pad to 16 B)
-    unsigned short *idx = reinterpret_cast<unsigned short *>(off + NB + 4);  // CHUNK, tuple indices grouped by bucket
-    u32 *wsum = reinterpret_cast<u32 *>(idx + ((CHUNK + 7) & ~7));           // NW scan scratch
+    u64 *ent = reinterpret_cast<u64 *>(smem);                                // CHUNK entries {key48 | idx16}, bucket order
+    u64 *rid = ent;                                                          // ... later CHUNK build rowIDs, arrival order
+    u32 *off32 = reinterpret_cast<u32 *>(ent + CHUNK);                       // NB/2 + 2 words of two 16-bit halves
+    const unsigned short *off16 = reinterpret_cast<const unsigned short *>(off32);   // off16[h], h in [0, NB]
+    u32 *wsum = off32 + NB / 2 + 2;                                          // NW scan scratch
     u32 *wtot = wsum + NW;                                                   // NW match totals
     u64 *gres = reinterpret_cast<u64 *>(wtot + NW);                          // 1
 
@@ -1086,163 +1095,271 @@ k_join_ps(const Tup *__restrict__ R, const Tup *__restrict__ S, const JoinTask *
     const Tup *__restrict__ P = (build_is_S ? R : S) + task.pbeg;
     const u32 nb = task.blen, np = task.plen;                                // np <= THREADS * EPT (host: probe_split)
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-
-    // the task's whole probe side: resident in registers across every build chunk.  Slot k of this thread is probe
-    // tuple k * THREADS + tid; slots k < nv are valid (one compare against a constant per use; invalid slots load
-    // tuple `tid` again, so no register is ever undefined).
+    const int rb = radix_bits;
+    const unsigned long long lt = (1ull << lane) - 1ull;
+    // slot k of this thread is probe tuple k * THREADS + tid; slots k < nv are valid
     const int nv = np > (u32)tid ? (int)((np - (u32)tid + THREADS - 1) / THREADS) : 0;
-    Tup p[EPT];
-#pragma unroll
-    for (int k = 0; k < EPT; k++) p[k] = P[k < nv ? (u32)k * THREADS + tid : (np > (u32)tid ? (u32)tid : 0u)];
 
+    const int tid0 = tid, nv0 = nv;
     for (u32 cb = 0; cb < nb; cb += CHUNK) {
         const u32 nc = (nb - cb < (u32)CHUNK) ? nb - cb : (u32)CHUNK;
-        // Everything derived from the probe registers alone (bucket hashes, range predicates of the 16 slots) is
-        // invariant across chunks and would be hoisted out of this loop into ~50 more live registers (measured:
-        // 100 VGPRs spilled); two opaque copies keep those cheap recomputations inside the iteration.
-        int nvc = nv, rbc = radix_bits;
-        asm volatile("" : "+v"(nvc), "+s"(rbc));
+        // Addresses and range predicates of the 35 build and 32 probe slots depend only on the thread index: left
+        // alone they are hoisted out of this loop into > 100 live registers.  An opaque copy of the thread index per
+        // iteration keeps those one-instruction recomputations next to their uses.
+        int tid = tid0, nv = nv0;
+        asm volatile("" : "+v"(tid), "+v"(nv));
         const int nvb = nc > (u32)tid ? (int)((nc - (u32)tid + THREADS - 1) / THREADS) : 0;   // valid build slots
-        // ---- build: tuples to LDS in arrival order, counting sort of their indices by hash bucket ----
+        // ---- build: count per bucket (rank = value before the add), keep {key | rank} and the rowID in registers ----
 #pragma unroll
-        for (int j = 0; j < PER; j++) off[tid * PER + j] = 0;
-        if (tid == 0) off[NB] = 0;
+        for (int j = 0; j < WPT; j++) off32[tid * WPT + j] = 0;
+        if (tid == 0) off32[NB / 2] = 0;
         __syncthreads();
-        u32 hr[BPT];                                                         // bucket | rank << BBITS
+        u64 kr[BPT];
 #pragma unroll
-        for (int k0 = 0; k0 < BPT; k0 += 4) {                                // 4 x 16 B loads in flight per lane
-            Tup bt[4];
+        for (int k0 = 0; k0 < BPT; k0 += BB) {
+            Tup bt[BB];
 #pragma unroll
-            for (int k = k0; k < k0 + 4 && k < BPT; k++) bt[k - k0] = B[cb + (k < nvb ? (u32)k * THREADS + tid : 0u)];
+            for (int k = k0; k < k0 + BB; k++) bt[k - k0] = B[cb + (k < nvb ? (u32)k * THREADS + tid : 0u)];
 #pragma unroll
-            for (int k = k0; k < k0 + 4 && k < BPT; k++) {
-                const u32 i = (u32)k * THREADS + tid;
+            for (int k = k0; k < k0 + BB; k++) {
+                const u64 key = bt[k - k0].payload >> rb;
+                kr[k] = key << 16;
                 if (k < nvb) {
-                    tup[i] = bt[k - k0];
-                    const u32 h = bj_bucket<BBITS>(bt[k - k0].payload, rbc);
-                    hr[k] = h | (atomicAdd(&off[h], 1u) << BBITS);
+                    const u32 h = ct_bucket<BBITS>(key), sh = (h & 1u) * 16u;
+                    kr[k] |= (atomicAdd(&off32[h >> 1], 1u << sh) >> sh) & 0xFFFFu;
                 }
             }
         }
+        stamp();                                                             // 1: build side loaded and counted
         __syncthreads();
-        {   // in-place exclusive scan of the NB bucket counts
-            u32 c[PER], loc = 0;
+        {   // in-place exclusive scan of the NB packed bucket counts
+            u32 wd[WPT], loc = 0;
 #pragma unroll
-            for (int j = 0; j < PER; j++) { c[j] = off[tid * PER + j]; loc += c[j]; }
+            for (int j = 0; j < WPT; j++) { wd[j] = off32[tid * WPT + j]; loc += (wd[j] & 0xFFFFu) + (wd[j] >> 16); }
             u32 tot;
             u32 ex = block_excl_scan<THREADS>(loc, wsum, tot);
 #pragma unroll
-            for (int j = 0; j < PER; j++) { off[tid * PER + j] = ex; ex += c[j]; }
-            if (tid == THREADS - 1) off[NB] = ex;
+            for (int j = 0; j < WPT; j++) {
+                const u32 c0 = wd[j] & 0xFFFFu, c1 = wd[j] >> 16;
+                off32[tid * WPT + j] = ex | ((ex + c0) << 16);
+                ex += c0 + c1;
+            }
+            if (tid == THREADS - 1) off32[NB / 2] = ex;                      // off16[NB] = nc
         }
         __syncthreads();
+        u32 ppos[(BPT + 1) / 2];                                             // table position of each build tuple, two per register
+        {
+            int tp = tid0;                                                   // (see above: no shared index temporaries)
+            asm volatile("" : "+v"(tp));
+            const int nvp = nc > (u32)tp ? (int)((nc - (u32)tp + THREADS - 1) / THREADS) : 0;
 #pragma unroll
-        for (int k = 0; k < BPT; k++)
-            if (k < nvb) idx[off[hr[k] & (NB - 1)] + (hr[k] >> BBITS)] = (unsigned short)((u32)k * THREADS + tid);
+            for (int k = 0; k < BPT; k++) {
+                u32 pos = 0;
+                if (k < nvp) {
+                    const u64 key = kr[k] >> 16;
+                    pos = off16[ct_bucket<BBITS>(key)] + ((u32)kr[k] & 0xFFFFu);
+                    ent[pos] = (key << 16) | (u64)((u32)k * THREADS + tp);
+                }
+                if (k & 1) ppos[k >> 1] |= pos << 16; else ppos[k >> 1] = pos;
+            }
+        }
         __syncthreads();
+        stamp();                                                             // 2: table ready
 
-        // ---- probe, count phase: mi[k] = index of the matching build tuple (FK case), multi = slots where some
-        // lane of this wavefront has more than one match (duplicates on the build side: slow path) ----
-        u32 mi[(EPT + 1) / 2];                                               // two 16-bit indices per register
-        u32 multi = 0, wave_total = 0;
+        // ---- probe: the task's probe tuples stream through a ring of DEPTH register tiles --------------------------
+        u64 prid[EPT];                                                       // probe rowIDs
+        u32 mi[EPT];                                                         // matches of a slot: first table position of its bucket |
+                                                                             // (bit b: entry lo + b matches) << 16; 0 = none
+        u32 deferred = 0;                                                    // wave-uniform: slots left to the generic loop
+        u32 ctot = 0;                                                        // matches of this lane
+        Tup ring[DEPTH][PT];
+        asm volatile("" : "+v"(tid), "+v"(nv));
 #pragma unroll
-        for (int k = 0; k < EPT; k++) {
-            u32 lo = 0, hi = 0;
-            if (k < nvc) {
-                const u32 h = bj_bucket<BBITS>(p[k].payload, rbc);
-                lo = off[h]; hi = off[h + 1];
+        for (int t = 0; t < DEPTH && t < NT; t++)
+#pragma unroll
+            for (int s = 0; s < PT; s++) ring[t][s] = P[t * PT + s < nv ? (u32)(t * PT + s) * THREADS + tid : 0u];
+#pragma unroll
+        for (int t = 0; t < NT; t++) {
+            u32 khi[PT], klo[PT];                                            // key << 16, to compare with an entry's upper 48 bits
+            u32 lo[PT], len[PT], m[PT], maxlen = 0;
+#pragma unroll
+            for (int s = 0; s < PT; s++) {
+                const int k = t * PT + s;
+                prid[k] = ring[t % DEPTH][s].key;
+                const u64 key = ring[t % DEPTH][s].payload >> rb;
+                const u32 h = ct_bucket<BBITS>(key);
+                khi[s] = (u32)(key >> 16); klo[s] = (u32)key << 16;
+                lo[s] = 0; len[s] = 0; m[s] = 0;
+                if (k < nv) { lo[s] = off16[h]; len[s] = off16[h + 1] - lo[s]; }
+                maxlen = len[s] > maxlen ? len[s] : maxlen;
             }
-            u32 c = 0, m = PS_NONE;
-            if (__ballot(hi - lo > BJ_HEAVY) == 0) {                         // short buckets everywhere: inline
-                for (u32 j = lo; j < hi; j++) {
-                    const u32 bi = idx[j];
-                    if (tup[bi].payload == p[k].payload) { c++; m = bi; }
-                }
-            } else {
-                // a few lanes facing a long bucket (duplicate-heavy build side) would serialise the workgroup:
-                // those buckets are scanned by all 64 lanes together
-                unsigned long long heavy = __ballot(hi - lo > BJ_HEAVY);
-                const bool coop = __popcll(heavy) <= BJ_HEAVY_LANES;
-                if (!coop || hi - lo <= BJ_HEAVY) {
-                    c = ps_count_bucket(tup, idx, lo, hi, p[k].payload);
-                    if (c) m = 0;                                            // marks "matched"; c > 1 or slow path re-scans
-                    if (c == 1) {                                            // recover the index for the FK write path
-                        for (u32 j = lo; j < hi; j++) { const u32 bi = idx[j]; if (tup[bi].payload == p[k].payload) m = bi; }
-                    }
-                }
-                if (coop) {
-                    while (heavy) {
-                        const int leader = __ffsll((long long)heavy) - 1;
-                        heavy &= heavy - 1;
-                        const u64 key = bj_readlane64(p[k].payload, leader);
-                        const u32 l = __builtin_amdgcn_readlane(lo, leader), hh = __builtin_amdgcn_readlane(hi, leader);
-                        u32 tot = 0, last = PS_NONE;
-                        for (u32 j = l; j < hh; j += 64) {
-                            u32 bi = 0;
-                            bool mt = false;
-                            if (j + lane < hh) { bi = idx[j + lane]; mt = tup[bi].payload == key; }
-                            const unsigned long long bal = __ballot(mt);
-                            tot += (u32)__popcll(bal);
-                            if (bal) last = __builtin_amdgcn_readlane(bi, __ffsll((long long)bal) - 1);
-                        }
-                        if (lane == leader) { c = tot; m = tot ? last : PS_NONE; }
+            if (t + DEPTH < NT) {                                            // the slot is free: next tile on its way
+#pragma unroll
+                for (int s = 0; s < PT; s++)
+                    ring[t % DEPTH][s] = P[(t + DEPTH) * PT + s < nv ? (u32)((t + DEPTH) * PT + s) * THREADS + tid : 0u];
+            }
+            const bool longb = __ballot(maxlen > CT_MASK_BITS) != 0;         // a long bucket somewhere: the generic loop
+            if (!longb) {
+                for (u32 j = 0; __ballot(j < maxlen) != 0; j++) {            // PT independent LDS reads per round
+#pragma unroll
+                    for (int s = 0; s < PT; s++) {
+                        const u64 e = ent[lo[s] + j];                        // (past the bucket's end: some other entry, ignored)
+                        const u32 xl = (u32)e ^ klo[s], xh = (u32)(e >> 32) ^ khi[s];
+                        if (j < len[s] && xh == 0 && xl < 0x10000u) m[s] |= 0x10000u << j;
                     }
                 }
             }
-            if (c == 0) m = PS_NONE;
-            if (k & 1) mi[k >> 1] |= m << 16; else mi[k >> 1] = m;
-            if (__ballot(c > 1) == 0) {
-                wave_total += (u32)__popcll(__ballot(c != 0));
-            } else {
-                multi |= 1u << k;
-                u32 r = c;
 #pragma unroll
-                for (int o2 = 32; o2 > 0; o2 >>= 1) r += __shfl_xor(r, o2, 64);
-                wave_total += r;
+            for (int s = 0; s < PT; s++) {
+                const int k = t * PT + s;
+                if (longb) { deferred |= 1u << k; m[s] = 0; }
+                ctot += (u32)__popc(m[s] >> 16);
+                mi[k] = m[s] ? (m[s] | lo[s]) : 0u;
             }
         }
+        u32 wave_total = ctot;                                               // matches found by this wavefront on the fast path
+#pragma unroll
+        for (int o2 = 32; o2 > 0; o2 >>= 1) wave_total += __shfl_xor(wave_total, o2, 64);
+
+        stamp();                                                             // 3: this wavefront's probes done
+        // ---- generic loop: (wavefront, slot)s with duplicates on the build side or long buckets.  Own output range,
+        // build rowIDs from the partition in global memory; the table is still valid here. ----
+        while (deferred) {
+            const int k = __ffs((int)deferred) - 1;
+            deferred &= deferred - 1;
+            const Tup pt = P[k < nv ? (u32)k * THREADS + tid : 0u];
+            const u64 key = pt.payload >> rb;
+            u32 lo = 0, hi = 0;
+            if (k < nv) { const u32 h = ct_bucket<BBITS>(key); lo = off16[h]; hi = off16[h + 1]; }
+            unsigned long long heavy = __ballot(hi - lo > BJ_HEAVY);
+            const bool coop = heavy != 0 && __popcll(heavy) <= BJ_HEAVY_LANES;
+            const bool serial = !coop || hi - lo <= BJ_HEAVY;
+            u32 c = 0;
+            if (serial) for (u32 j = lo; j < hi; j++) c += ((ent[j] >> 16) == key) ? 1u : 0u;
+            if (coop) {
+                unsigned long long hv = heavy;
+                while (hv) {
+                    const int leader = __ffsll((long long)hv) - 1;
+                    hv &= hv - 1;
+                    const u64 lkey = bj_readlane64(key, leader);
+                    const u32 l = __builtin_amdgcn_readlane(lo, leader), hh = __builtin_amdgcn_readlane(hi, leader);
+                    u32 tot = 0;
+                    for (u32 j = l; j < hh; j += 64) {
+                        const bool mt = (j + lane < hh) && (ent[j + lane] >> 16) == lkey;
+                        tot += (u32)__popcll(__ballot(mt));
+                    }
+                    if (lane == leader) c = tot;
+                }
+            }
+            const u32 ic = wave_incl_scan(c, lane);
+            const u32 tot = __shfl(ic, 63, 64);
+            if (tot == 0) continue;
+            u64 base = 0;
+            if (lane == 0) base = atomicAdd(out_count, (u64)tot);
+            base = bj_readlane64(base, 0);
+            if (out == nullptr) continue;
+            u64 o = base + ic - c;
+            if (c && serial) {
+                for (u32 j = lo; j < hi; j++) {
+                    const u64 e = ent[j];
+                    if ((e >> 16) == key) {
+                        if (o < out_capacity) {
+                            const u64 br = B[cb + ((u32)e & 0xFFFFu)].key;
+                            Pair pr;
+                            if (build_is_S) { pr.r = pt.key; pr.s = br; } else { pr.r = br; pr.s = pt.key; }
+                            out[o] = pr;
+                        }
+                        o++;
+                    }
+                }
+            }
+            if (coop) {
+                unsigned long long hv = heavy;
+                while (hv) {
+                    const int leader = __ffsll((long long)hv) - 1;
+                    hv &= hv - 1;
+                    const u64 lkey = bj_readlane64(key, leader), lprid = bj_readlane64(pt.key, leader);
+                    u64 ob = bj_readlane64(o, leader);
+                    const u32 l = __builtin_amdgcn_readlane(lo, leader), hh = __builtin_amdgcn_readlane(hi, leader);
+                    for (u32 j = l; j < hh; j += 64) {
+                        u64 e = 0;
+                        bool mt = false;
+                        if (j + lane < hh) { e = ent[j + lane]; mt = (e >> 16) == lkey; }
+                        const unsigned long long bal = __ballot(mt);
+                        const u64 dst = ob + (u64)__popcll(bal & lt);
+                        if (mt && dst < out_capacity) {
+                            const u64 br = B[cb + ((u32)e & 0xFFFFu)].key;
+                            Pair pr;
+                            if (build_is_S) { pr.r = lprid; pr.s = br; } else { pr.r = br; pr.s = lprid; }
+                            out[dst] = pr;
+                        }
+                        ob += (u64)__popcll(bal);
+                    }
+                }
+            }
+        }
+
+        // ---- output of the FK case: table -> build rowIDs, one reservation per task, pairs completed from LDS ------
+        stamp();                                                             // 4: generic loop done
+        // The build rowIDs are needed once the table is dead.  Holding them in registers from the build phase on would
+        // take 70 more VGPRs through the probe phase (tried: the allocator spills them at their definition and the
+        // build loads serialise behind the scratch stores); they are fetched again here instead, 8 of every 16 bytes of
+        // a partition this CU streamed a few microseconds ago, while the barrier and the reservation go on.
+        u64 brid[BPT];
+        {
+            int tq = tid0;
+            asm volatile("" : "+v"(tq));
+            const int nvq = nc > (u32)tq ? (int)((nc - (u32)tq + THREADS - 1) / THREADS) : 0;
+#pragma unroll
+            for (int k = 0; k < BPT; k++) brid[k] = B[cb + (k < nvq ? (u32)k * THREADS + tq : 0u)].key;
+        }
+        stamp();                                                             // 5: rowID loads issued
         if (lane == 0) wtot[w] = wave_total;
-        __syncthreads();
-        // every wavefront scans the NW wave totals itself
+        __syncthreads();                                                     // every wavefront is done with the table
+        stamp();                                                             // 6: barrier passed
+        {
+            int td = tid0;
+            asm volatile("" : "+v"(td));
+            const int nvd = nc > (u32)td ? (int)((nc - (u32)td + THREADS - 1) / THREADS) : 0;
+#pragma unroll
+            for (int k = 0; k < BPT; k++)
+                if (k < nvd) rid[(k & 1) ? (ppos[k >> 1] >> 16) : (ppos[k >> 1] & 0xFFFFu)] = brid[k];   // table order
+        }
+        stamp();                                                             // 7: rowIDs in LDS
         const u32 mine = lane < NW ? wtot[lane] : 0u;
         const u32 inc = wave_incl_scan(mine, lane);
         const u32 chunk_total = __shfl(inc, NW - 1, 64);
         const u32 wbase = __shfl(inc - mine, w, 64);
         if (tid == 0 && chunk_total) *gres = atomicAdd(out_count, (u64)chunk_total);
         __syncthreads();
-        if (chunk_total && out != nullptr && wave_total) {
+        stamp();                                                             // 8: output reserved
+        if (out != nullptr && wave_total) {
             u64 o = *gres + wbase;                                           // next output slot of this wavefront
-            const unsigned long long lt = (1ull << lane) - 1ull;
 #pragma unroll
             for (int k = 0; k < EPT; k++) {
-                const u32 m = (k & 1) ? (mi[k >> 1] >> 16) : (mi[k >> 1] & 0xFFFFu);
-                if (!(multi & (1u << k))) {                                  // FK case: at most one match per lane
-                    const unsigned long long bal = __ballot(m != PS_NONE);
-                    if (m != PS_NONE) {
+                const u32 lo = mi[k] & 0xFFFFu;
+                u32 mask = mi[k] >> 16;
+                // round r stores the (r+1)-th match of every lane that has one: ballot + mbcnt compaction, consecutive
+                // lanes -> consecutive pairs.  One round in the FK case; no cross-lane scan with duplicates either.
+                for (unsigned long long bal = __ballot(mask != 0); bal != 0; bal = __ballot(mask != 0)) {
+                    if (mask) {
                         const u64 dst = o + (u64)__popcll(bal & lt);
+                        const u32 bpos = (u32)__ffs((int)mask) - 1;
+                        mask &= mask - 1;
                         if (dst < out_capacity) {
-                            const u64 brid = tup[m].key;
+                            const u64 br = rid[lo + bpos];
                             Pair pr;
-                            if (build_is_S) { pr.r = p[k].key; pr.s = brid; }      // orderFlag, Result.cpp:64-68
-                            else            { pr.r = brid; pr.s = p[k].key; }
+                            if (build_is_S) { pr.r = prid[k]; pr.s = br; }      // orderFlag, Result.cpp:64-68
+                            else            { pr.r = br; pr.s = prid[k]; }
                             out[dst] = pr;
                         }
                     }
                     o += (u64)__popcll(bal);
-                } else {                                                     // duplicates: recount, scan, re-walk the bucket
-                    u32 lo = 0, hi = 0;
-                    if (m != PS_NONE) {
-                        const u32 h = bj_bucket<BBITS>(p[k].payload, rbc);
-                        lo = off[h]; hi = off[h + 1];
-                    }
-                    const u32 c = (m != PS_NONE) ? ps_count_bucket(tup, idx, lo, hi, p[k].payload) : 0u;
-                    const u32 ic = wave_incl_scan(c, lane);
-                    if (c) ps_emit_bucket(tup, idx, lo, hi, p[k].payload, p[k].key, build_is_S, out, o + ic - c, out_capacity);
-                    o += (u64)__shfl(ic, 63, 64);
                 }
             }
         }
-        __syncthreads();         // the table is rebuilt by the next chunk
+        stamp();                                                             // 9: this wavefront's pairs stored (issued)
+        if (cb + CHUNK < nb) __syncthreads();                                // the next chunk rebuilds the table over rid
     }
 }
 
@@ -1341,15 +1458,10 @@ static int wc_threads_for(int bits)
 
 constexpr int BJ2_THREADS = 1024, BJ2_CHUNK = 8448, BJ2_BUCKET_BITS = 12, BJ2_EPT = 4;
 
-// oversized partitions: the probe-stationary kernel unless RHJ_JOIN_BIG=bkt asks for round 1's chunk-outer geometry
-// (kept as the measured baseline of DESIGN.md §4.2)
-bool join_big_is_ps()
-{
-    static const bool ps = !(getenv("RHJ_JOIN_BIG") && getenv("RHJ_JOIN_BIG")[0] == 'b');
-    return ps;
-}
-u32 join_big_probe_split() { return join_big_is_ps() ? (u32)(PS_THREADS * PS_EPT) : 0u; }
-u32 join_big_table_tuples() { return join_big_is_ps() ? (u32)PS_CHUNK : (u32)BJ2_CHUNK; }
+// probe tuples per task / build tuples per table of each join kernel (host plan)
+u32 join_probe_split(int kind) { return kind == JK_CT ? (u32)(CT_THREADS * CT_EPT) : 0u; }
+u32 join_table_tuples(int kind) { return kind == JK_CT ? (u32)CT_CHUNK : kind == JK_BKT_BIG ? (u32)BJ2_CHUNK : (u32)BJ_CHUNK; }
+int join_ct_min_radix_bits() { return CT_MIN_RADIX_BITS; }
 
 static size_t bj_lds_bytes(int threads, int chunk, int bbits)
 {
@@ -1366,9 +1478,9 @@ static int current_device_slot()
     return dev;
 }
 
-static size_t ps_lds_bytes(int threads, int chunk, int bbits)
+static size_t ct_lds_bytes()
 {
-    return (size_t)chunk * 16 + ((size_t)(1 << bbits) + 4) * 4 + (size_t)((chunk + 7) & ~7) * 2 + (size_t)(threads / 64) * 8 + 16;
+    return (size_t)CT_CHUNK * 8 + ((size_t)(1 << CT_BUCKET_BITS) / 2 + 2 + 2 * (CT_THREADS / 64)) * 4 + 16;
 }
 
 static void allow_big_lds()
@@ -1387,9 +1499,10 @@ static void allow_big_lds()
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_join_bkt<BJ2_THREADS, BJ2_CHUNK, BJ2_BUCKET_BITS, BJ2_EPT>),
                               hipFuncAttributeMaxDynamicSharedMemorySize,
                               (int)bj_lds_bytes(BJ2_THREADS, BJ2_CHUNK, BJ2_BUCKET_BITS));
-    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_join_ps<PS_THREADS, PS_CHUNK, PS_BUCKET_BITS, PS_EPT>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize,
-                              (int)ps_lds_bytes(PS_THREADS, PS_CHUNK, PS_BUCKET_BITS));
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_join_ct<CT_THREADS, CT_CHUNK, CT_BUCKET_BITS, CT_EPT, false>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)ct_lds_bytes());
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_join_ct<CT_THREADS, CT_CHUNK, CT_BUCKET_BITS, CT_EPT, true>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)ct_lds_bytes());
     });
 }
 
@@ -1499,37 +1612,68 @@ void launch_prefix(hipStream_t st, const u64 *d_hist, u64 nbins, u64 *d_start)
 }
 
 void launch_make_tasks(hipStream_t st, const u64 *d_startR, const u64 *d_startS, u64 nparts, u32 probe_split,
-                       JoinTask *d_tasks, u32 *d_ntasks, u32 max_tasks, u64 *d_stats, bool big_tables)
+                       JoinTask *d_tasks, u32 *d_ntasks, u32 max_tasks, u64 *d_stats, int kind)
 {
     u64 g = (nparts + 255) / 256;
     if (g > 1024) g = 1024;
     hipLaunchKernelGGL(k_part_max, dim3((unsigned)g), dim3(256), 0, st, d_startR, d_startS, nparts, d_stats);   // d_stats zeroed by the caller
     hipLaunchKernelGGL(k_make_tasks, dim3((unsigned)((nparts + 1023) / 1024)), dim3(1024), 0, st, d_startR, d_startS,
                        nparts, probe_split, d_tasks, d_ntasks, max_tasks, d_stats,
-                       big_tables ? join_big_table_tuples() : (u32)BJ_CHUNK);
+                       join_table_tuples(kind));
 }
 
 void launch_join(hipStream_t st, const void *d_R, const u64 *d_startR, const void *d_S, const u64 *d_startS,
                  const JoinTask *d_tasks, const u32 *d_ntasks, u32 grid, int radix_bits,
-                 void *d_out, u64 out_capacity, u64 *d_out_count, bool big_tables)
+                 void *d_out, u64 out_capacity, u64 *d_out_count, int kind)
 {
     if (grid == 0) return;
     allow_big_lds();
-    if (!big_tables) {
+    if (kind == JK_BKT) {
         hipLaunchKernelGGL((k_join_bkt<BJ_THREADS, BJ_CHUNK, BJ_BUCKET_BITS, BJ_EPT>), dim3(grid), dim3(BJ_THREADS),
                            bj_lds_bytes(BJ_THREADS, BJ_CHUNK, BJ_BUCKET_BITS), st, (const Tup *)d_R, (const Tup *)d_S,
                            d_tasks, d_ntasks, radix_bits, (Pair *)d_out, out_capacity, d_out_count);
         return;
     }
-    if (join_big_is_ps()) {
-        hipLaunchKernelGGL((k_join_ps<PS_THREADS, PS_CHUNK, PS_BUCKET_BITS, PS_EPT>), dim3(grid), dim3(PS_THREADS),
-                           ps_lds_bytes(PS_THREADS, PS_CHUNK, PS_BUCKET_BITS), st, (const Tup *)d_R, (const Tup *)d_S,
+    if (kind == JK_BKT_BIG) {
+        hipLaunchKernelGGL((k_join_bkt<BJ2_THREADS, BJ2_CHUNK, BJ2_BUCKET_BITS, BJ2_EPT>), dim3(grid), dim3(BJ2_THREADS),
+                           bj_lds_bytes(BJ2_THREADS, BJ2_CHUNK, BJ2_BUCKET_BITS), st, (const Tup *)d_R, (const Tup *)d_S,
                            d_tasks, d_ntasks, radix_bits, (Pair *)d_out, out_capacity, d_out_count);
         return;
     }
-    hipLaunchKernelGGL((k_join_bkt<BJ2_THREADS, BJ2_CHUNK, BJ2_BUCKET_BITS, BJ2_EPT>), dim3(grid), dim3(BJ2_THREADS),
-                       bj_lds_bytes(BJ2_THREADS, BJ2_CHUNK, BJ2_BUCKET_BITS), st, (const Tup *)d_R, (const Tup *)d_S,
-                       d_tasks, d_ntasks, radix_bits, (Pair *)d_out, out_capacity, d_out_count);
+    static const bool want_stamps = getenv("RHJ_CT_STAMPS") != nullptr;
+    if (want_stamps) {                                                       // tuning aid: phase timeline of the first workgroups
+        const u32 nw = grid < 4096 ? grid : 4096;
+        u64 *d_st = nullptr;
+        if (hipMalloc(&d_st, (size_t)nw * CT_NSTAMP * 8) != hipSuccess) return;
+        (void)hipMemsetAsync(d_st, 0, (size_t)nw * CT_NSTAMP * 8, st);
+        hipLaunchKernelGGL((k_join_ct<CT_THREADS, CT_CHUNK, CT_BUCKET_BITS, CT_EPT, true>), dim3(grid), dim3(CT_THREADS),
+                           ct_lds_bytes(), st, (const Tup *)d_R, (const Tup *)d_S, d_tasks, d_ntasks, radix_bits,
+                           (Pair *)d_out, out_capacity, d_out_count, d_st, nw);
+        std::vector<u64> h((size_t)nw * CT_NSTAMP);
+        (void)hipMemcpyAsync(h.data(), d_st, h.size() * 8, hipMemcpyDeviceToHost, st);
+        (void)hipStreamSynchronize(st);
+        (void)hipFree(d_st);
+        double acc[CT_NSTAMP] = {};
+        u32 used = 0;
+        for (u32 g = 256; g < nw; g++) {                                     // skip the first wave of workgroups (cold start)
+            const u64 *r = &h[(size_t)g * CT_NSTAMP];
+            if (!r[0] || !r[9] || r[10]) continue;                           // single-chunk tasks: 10 stamps
+            used++;
+            for (int i = 1; i < 10; i++) acc[i] += (double)(r[i] - r[i - 1]) * 0.01;  // 100 MHz -> us
+        }
+        if (used) {
+            static const char *nm[10] = {"", "desc+build.load", "sort", "probe", "generic", "rid.issue", "barrier", "rid.dump",
+                                         "reserve", "store"};
+            double tot = 0;
+            fprintf(stderr, "[k_join_ct timeline, us, mean of %u single-chunk workgroups]", used);
+            for (int i = 1; i < 10; i++) { fprintf(stderr, " %s=%.2f", nm[i], acc[i] / used); tot += acc[i] / used; }
+            fprintf(stderr, " total=%.2f\n", tot);
+        }
+        return;
+    }
+    hipLaunchKernelGGL((k_join_ct<CT_THREADS, CT_CHUNK, CT_BUCKET_BITS, CT_EPT, false>), dim3(grid), dim3(CT_THREADS),
+                       ct_lds_bytes(), st, (const Tup *)d_R, (const Tup *)d_S, d_tasks, d_ntasks, radix_bits,
+                       (Pair *)d_out, out_capacity, d_out_count, (u64 *)nullptr, 0u);
 }
 
 static unsigned stream_grid(u64 n)

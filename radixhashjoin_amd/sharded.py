@@ -99,9 +99,10 @@ class ShardedJoin:
         via_host = mine.is_cuda and dist.get_backend(self.group) == "gloo"   # rehearsal: several ranks on one GPU
         if via_host:
             mine = mine.cpu()
-        allh = torch.empty((self.world,) + tuple(mine.shape), dtype=mine.dtype, device=mine.device)
+        mine = mine.reshape(-1).contiguous()
+        allh = torch.empty(self.world * mine.numel(), dtype=mine.dtype, device=mine.device)
         dist.all_gather_into_tensor(allh, mine, group=self.group)
-        allh = allh.cpu()                                                    # host sync: sizes must be known
+        allh = allh.cpu().view(self.world, 2, self.nclasses)                 # host sync: sizes must be known
         if self.balance:
             self.cuts = balanced_cuts(allh.sum(dim=(0, 1)).tolist(), self.world)
         lo, hi = self.cuts[self.rank], self.cuts[self.rank + 1]

@@ -1,0 +1,174 @@
+"""GPU suite: the bucket-join kernels for partitions whose build side does not fit one 16 B/tuple LDS table --
+explicit plans with too few radix bits (BASELINE config 3 names 8+8 bits at 10^9 tuples: 15 K-tuple partitions) and
+inputs beyond 2^30 tuples:
+    kernel 1  k_join_bkt<1024, 8448>   16-byte entries, build side in chunks, probe side re-read per chunk (any plan)
+    kernel 2  k_join_ct                8-byte {48-bit key | index} entries, both sides read once (plans removing >= 16 bits)
+Reference semantics: JoinJob::run + Result::join_buckets (JobScheduler.cpp:186-192, Result.cpp:43-76): every
+(rowR,rowS) with equal payloads, build side = smaller bucket.  Checked against the CPU oracle (sorted pair sets) and, at
+10^9 tuples, by count + checksum against the closed form.  rhj_set_option("join.big_tables", 1) makes the engine use
+these kernels whatever the partition sizes, so that small, oracle-sized inputs reach them."""
+import numpy as np
+import pytest
+
+from oracle.pyoracle import PAIR, TUPLE, sorted_pairs
+from radixhashjoin_amd import Engine, Opts
+from radixhashjoin_amd.binding import GEN_CONST, GEN_R, GEN_S_UNIFORM, GEN_S_ZIPF
+
+pytestmark = pytest.mark.gpu
+BKT_BIG, CT = 1, 2
+
+
+@pytest.fixture(scope="module", params=[BKT_BIG, CT], ids=["bkt_big", "compact_table"])
+def big(request):
+    e = Engine(0)
+    e.set_option("join.big_tables", 1)
+    e.set_option("join.big_kernel", request.param)
+    yield e
+    e.close()
+
+
+def rel(rng, n, values, key0=0):
+    t = np.empty(n, dtype=TUPLE)
+    t["key"] = rng.permutation(n).astype(np.uint64) + np.uint64(key0)
+    t["payload"] = values
+    return t
+
+
+def few_partitions(values, nlow):
+    """payload = join value << 16 | one of `nlow` 16-bit patterns chosen BY the value (the same on both sides of a
+    join): a 16-bit radix plan then yields `nlow` large partitions -- what 10^9 tuples give every partition -- from an
+    oracle-sized input"""
+    lows = np.random.default_rng(nlow).permutation(1 << 16)[:nlow].astype(np.uint64)
+    return (values << np.uint64(16)) | lows[(values % np.uint64(nlow)).astype(np.int64)]
+
+
+def check(engine, oracle, R, S, plan):
+    got = engine.join(R, S, opts=plan)
+    exp = oracle.join(R, S)
+    assert len(got) == len(exp)
+    assert np.array_equal(sorted_pairs(got), sorted_pairs(exp))
+
+
+@pytest.mark.parametrize("nR,nS,nlow", [(60_000, 200_000, 3),        # 20 K build / 66 K probe per partition: 2 chunks, 5 tasks
+                                        (200_000, 50_000, 4),        # build on S (the smaller bucket), pairs stay (rowR,rowS)
+                                        (17_920, 16_384, 1),         # exactly one table, exactly one task
+                                        (17_921, 16_385, 1),         # one tuple beyond each
+                                        (300_000, 300_000, 1500)])   # 200-tuple partitions through the same kernels
+def test_pkfk_16_bit_plan(big, oracle, nR, nS, nlow):
+    rng = np.random.default_rng(nR + nS)
+    rv = rng.permutation(1 << 22)[:nR].astype(np.uint64)
+    R = rel(rng, nR, few_partitions(rv, nlow))
+    S = rel(rng, nS, R["payload"][rng.integers(0, nR, nS)], key0=1 << 40)
+    S["payload"][::97] ^= np.uint64(1 << 40)                        # some probe tuples match nothing
+    check(big, oracle, R, S, Opts(2, 8, 8))
+
+
+@pytest.mark.parametrize("plan", [Opts(2, 8, 8), Opts(2, 9, 9), Opts(2, 10, 10)])
+def test_generated_inputs_forced_big(big, oracle, plan):
+    R, S = oracle.gen_R(400_000), oracle.gen_S_counter(700_000, 400_000, 7)
+    check(big, oracle, R, S, plan)
+
+
+def test_duplicates_on_both_sides(big, oracle):
+    """several matches per probe tuple: the generic (wavefront, slot) loop; output far larger than the inputs"""
+    rng = np.random.default_rng(5)
+    R = rel(rng, 60_000, few_partitions(rng.integers(0, 9_000, 60_000).astype(np.uint64), 2))
+    S = rel(rng, 50_000, few_partitions(rng.integers(0, 9_000, 50_000).astype(np.uint64), 2), key0=1 << 40)
+    check(big, oracle, R, S, Opts(2, 8, 8))
+
+
+def test_long_buckets_cooperative_scan(big, oracle):
+    """a few join values repeated thousands of times on the BUILD side among unique ones: the lanes that hit them
+    face buckets far beyond BJ_HEAVY and are served by the whole wavefront"""
+    rng = np.random.default_rng(11)
+    nb = 30_000
+    vals = (rng.permutation(1 << 20)[:nb].astype(np.uint64) + np.uint64(1000)) << np.uint64(16)
+    vals[:2500] = 17 << 16                 # one hot value
+    vals[2500:3100] = 18 << 16             # another
+    B = rel(rng, nb, vals)
+    pv = (rng.permutation(1 << 20)[:90_000].astype(np.uint64) + np.uint64(1000)) << np.uint64(16)
+    pv[::9001] = 17 << 16                  # ten probe tuples hit the first hot value ...
+    pv[5::30_011] = 18 << 16               # ... three the second
+    P = rel(rng, 90_000, pv, key0=1 << 33)
+    check(big, oracle, B, P, Opts(2, 8, 8))   # B is the smaller side: build
+    check(big, oracle, P, B, Opts(2, 8, 8))   # roles swapped: pairs are (rowR,rowS) either way
+
+
+def test_all_equal_keys(big):
+    n, m = 20_000, 9_000
+    dR, dS = big.alloc(16 * n), big.alloc(16 * m)
+    big.generate(GEN_CONST, dR, n, 0, 99 << 16)
+    big.generate(GEN_CONST, dS, m, 0, 99 << 16)
+    assert big.join_dev(dR, n, dS, m, opts=Opts(2, 8, 8)) == n * m
+    dO = big.alloc(16 * 500_000)
+    assert big.join_dev(dR, n, dS, m, dO, 500_000, opts=Opts(2, 8, 8), allow_overflow=True) == n * m
+    part = dO.to_numpy(PAIR, 500_000)
+    assert part["keyR"].max() < n and part["keyS"].max() < m
+    assert len(np.unique(part["keyR"] * np.uint64(m) + part["keyS"])) == 500_000
+
+
+def test_full_width_rowids(big, oracle):
+    rng = np.random.default_rng(3)
+    n = 50_000
+    R = rel(rng, n, few_partitions(rng.permutation(1 << 30)[:n].astype(np.uint64), 2))
+    R["key"] = rng.integers(0, 1 << 63, n, dtype=np.uint64) * np.uint64(2) + np.uint64(1)
+    S = rel(rng, 80_000, R["payload"][rng.integers(0, n, 80_000)])
+    S["key"] = rng.integers(0, 1 << 63, 80_000, dtype=np.uint64) * np.uint64(2)
+    check(big, oracle, R, S, Opts(2, 8, 8))
+
+
+def test_under_partitioned_plans_use_the_chunked_kernel(big, oracle):
+    """fewer than 16 radix bits: keys do not fit 48 bits, the engine must take the 16-byte-entry kernel whatever
+    "join.big_kernel" says -- same pairs"""
+    R, S = oracle.gen_R(300_000), oracle.gen_S_counter(200_000, 300_000, 3)
+    for plan in (Opts(0), Opts(1, 4), Opts(2, 4, 4)):
+        check(big, oracle, R, S, plan)
+
+
+def test_skewed_probe_side(big):
+    nR, nS = 400_000, 2_000_000
+    dR, dS, dO = big.alloc(16 * nR), big.alloc(16 * nS), big.alloc(16 * nS)
+    big.generate(GEN_R, dR, nR, 0, nR)
+    big.generate(GEN_S_ZIPF, dS, nS, 0, nR, seed=3, theta_milli=900)
+    exp_n, exp_c = big.expected_pkfk(dS, nS)
+    for plan in (Opts(2, 8, 8), Opts(1, 3)):
+        assert big.join_dev(dR, nR, dS, nS, dO, nS, opts=plan) == exp_n == nS
+        assert big.pairs_checksum(dO, nS) == exp_c
+
+
+def test_bucket_join_stage_big_partitions(big, oracle):
+    """the JoinJob stage alone on four 75 K x 50 K partitions made by the oracle's own partitioner"""
+    R, S = oracle.gen_R(300_000, 100_000), oracle.gen_S_chain(200_000, 100_000)
+    def part2(T):
+        d = (T["payload"] & np.uint64(3)).astype(np.int64)
+        o = np.argsort(d, kind="stable")
+        return T[o], np.concatenate([[0], np.cumsum(np.bincount(d, minlength=4))]).astype(np.uint64)
+    Rp, sR = part2(R)
+    Sp, sS = part2(S)
+    exp = oracle.join(R, S)
+    dRp, dSp, dsR, dsS = big.to_device(Rp), big.to_device(Sp), big.to_device(sR), big.to_device(sS)
+    n = big.bucket_join(dRp, dsR, dSp, dsS, 4, 2)
+    assert n == len(exp)
+    dO = big.alloc(16 * n)
+    assert big.bucket_join(dRp, dsR, dSp, dsS, 4, 2, dO, n) == n
+    assert np.array_equal(sorted_pairs(dO.to_numpy(PAIR, n)), sorted_pairs(exp))
+
+
+@pytest.mark.parametrize("kind,plan", [(GEN_S_UNIFORM, Opts(2, 8, 8)), (GEN_S_ZIPF, Opts(2, 8, 8)), (GEN_S_ZIPF, Opts())])
+def test_one_billion_count_and_checksum(engine, kind, plan):
+    """BASELINE configs 3 and 4 at full size through rhj_join_dev with the engine's own kernel choice: 10^9 x 10^9,
+    exact count and order-insensitive checksum of the pair set against the closed form (itself pinned to the oracle
+    at 2-3 M tuples)"""
+    n = 1_000_000_000
+    free, _ = engine.mem_info()
+    if free < 16 * n * 6.5:
+        pytest.skip("not enough free HBM")
+    dR, dS, dO = engine.alloc(16 * n), engine.alloc(16 * n), engine.alloc(16 * n)
+    engine.generate(GEN_R, dR, n, 0, n)
+    engine.generate(kind, dS, n, 0, n, seed=42, theta_milli=900)
+    exp_n, exp_c = engine.expected_pkfk(dS, n)
+    assert engine.join_dev(dR, n, dS, n, dO, n, opts=plan) == exp_n == n
+    assert engine.pairs_checksum(dO, n) == exp_c
+    for b in (dR, dS, dO):
+        b.free()
+    engine.release_workspace()

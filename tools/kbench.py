@@ -21,6 +21,7 @@ ap.add_argument("--dist", default="uniform")
 ap.add_argument("--label", default="")
 ap.add_argument("--probe-split", type=int, default=0)
 ap.add_argument("--no-join", action="store_true", help="partition stage only (safe for ablations that corrupt outputs)")
+ap.add_argument("--join-only", action="store_true", help="partition once, then time rhj_bucket_join alone")
 a = ap.parse_args()
 
 e = rhj.Engine(0)
@@ -45,6 +46,22 @@ if a.no_join:
                       "scatter_ms": round(per["scatter"], 3), "scatter_GBs(32B/t)": round(32 * n / per["scatter"] / 1e6),
                       "scan_ms": round(per["scan"], 3)}))
     sys.exit(0)
+if a.join_only:
+    tb = a.bits1 + (a.bits2 if a.passes == 2 else 0)
+    pR, pS = e.alloc(16 * n), e.alloc(16 * n)
+    sR, sS = e.alloc(8 * ((1 << tb) + 1)), e.alloc(8 * ((1 << tb) + 1))
+    e.partition(dR, n, a.bits1, a.bits2 if a.passes == 2 else 0, pR, sR)
+    e.partition(dS, n, a.bits1, a.bits2 if a.passes == 2 else 0, pS, sS)
+    e.set_profiling(True)
+    ms = []
+    for _ in range(a.reps + 1):
+        cnt = e.bucket_join(pR, sR, pS, sS, 1 << tb, tb, dO, n, probe_split=a.probe_split)
+        ms.append(e.timings()["join"]["ms"])
+    ok = (cnt, e.pairs_checksum(dO, cnt)) == exp
+    ms = ms[1:]
+    print(json.dumps({"label": a.label or os.environ.get("RHJ_VARIANT", ""), "n": n, "bits": [a.bits1, a.bits2], "ok": ok,
+                      "join_ms": [round(x, 3) for x in ms], "join_GBs(48B/t)": round(48 * n / (sum(ms) / len(ms)) / 1e6)}))
+    sys.exit(0 if ok else 1)
 e.join_dev(dR, n, dS, n, dO, n, opts=opts)
 e.set_profiling(True)
 acc = {}

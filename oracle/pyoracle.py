@@ -129,15 +129,21 @@ class Oracle:
         return t
 
 
-def ref_available():
-    return os.path.exists(os.path.join(HERE, "_ref", "libref_rhj.so"))
+def _ref_lib(threads):
+    return os.path.join(HERE, "_ref", "libref_rhj.so" if threads == 8 else f"libref_rhj_{threads}t.so")
+
+
+def ref_available(threads=8):
+    return os.path.exists(_ref_lib(threads))
 
 
 class Reference:
-    """The real reference, compiled by oracle/Makefile into oracle/_ref/ (binary only)."""
+    """The real reference, compiled by oracle/Makefile into oracle/_ref/ (binary only).  threads = 8 is the reference as
+    shipped (NUM_OF_THREADS, JobScheduler.h:11); threads = 1 the build with that one macro patched in a /tmp copy of the
+    header (the CPU-baseline protocol times both)."""
 
-    def __init__(self):
-        self.lib = L = C.CDLL(os.path.join(HERE, "_ref", "libref_rhj.so"))
+    def __init__(self, threads=8):
+        self.lib = L = C.CDLL(_ref_lib(threads))
         L.ref_num_threads.restype = C.c_int
         L.ref_next_prime.restype = _sz
         L.ref_next_prime.argtypes = [_sz]

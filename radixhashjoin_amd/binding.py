@@ -163,6 +163,11 @@ class DeviceBuffer:
             pass
 
 
+_libc = C.CDLL(None)
+_libc.free.argtypes = [_vp]
+_libc_free = _libc.free
+
+
 class Engine:
     """One rhj_ctx: a HIP stream + HBM workspace on one GPU.  Not thread-safe (one per caller thread)."""
 
@@ -244,6 +249,18 @@ class Engine:
         else:
             assert n.value == 0
         return out
+
+    def join_count_only_page(self, R, S, opts=None):
+        """rhj_join exactly as the C++ mirror calls it, the result page freed right away (what ~Result does): for
+        timing the drop-in without numpy's copy of the pairs"""
+        R = np.ascontiguousarray(R, dtype=TUPLE)
+        S = np.ascontiguousarray(S, dtype=TUPLE)
+        page, n = _vp(), _u64()
+        self._chk(self.lib.rhj_join(self.ctx, R.ctypes.data, len(R), S.ctypes.data, len(S),
+                                    C.byref(opts) if opts is not None else None, C.byref(page), C.byref(n)))
+        if page.value:
+            _libc_free(_vp(page.value))
+        return n.value
 
     # ---- device-resident ------------------------------------------------------------------------
     def join_dev(self, d_R, nR, d_S, nS, d_out=None, capacity=0, opts=None, allow_overflow=False):

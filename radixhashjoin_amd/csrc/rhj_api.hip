@@ -222,9 +222,13 @@ int resolve_plan(u64 nR, u64 nS, const rhj_opts *in, rhj_opts *out)
             if (bits == 0) o.passes = 0;
             else if (bits <= 9) { o.passes = 1; o.bits1 = bits; }
             else {
-                // 9 bits per pass is the widest line-aligned write-combining scatter; beyond 18 bits the bucket join's
-                // 8448-tuple geometry / build chunks absorb the larger partitions (10-bit passes run at half the rate)
-                if (bits > 18) bits = 18;
+                // Two passes.  Up to 16 bits both histograms come from ONE read of the input (k_hist2d_units); a 17- or
+                // 18-bit plan re-reads each relation once more just to count (10.7 instead of 5.4 ms per 10^9-tuple join).
+                // Partitions that 16 bits leave larger than one 16-byte-entry table go to the compact-table bucket join
+                // (one 17920-entry table, both sides read once), which costs less than that extra read: measured at
+                // 10^9 x 10^9, 8+8 bits 43 ms against 49 ms for 9+9.  Beyond ~2.3 * 10^9 tuples per side its tables
+                // need chunks and 9+9 bits (the widest line-aligned write-combining scatter) takes over.
+                if (bits > 16) bits = nb <= 2 * (u64)65536 * 16800 ? 16 : 18;
                 o.passes = 2; o.bits1 = (bits + 1) / 2; o.bits2 = bits / 2;
             }
         }

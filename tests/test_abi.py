@@ -42,8 +42,11 @@ def test_plan_auto():
     assert P(4225, 10**6).passes == 1
     p = P(10**6, 10**6)
     assert (p.passes, p.bits1, p.bits2) == (1, 8, 0)    # BASELINE config 2: 1M x 1M, 8-bit, single pass
+    p = P(2 * 10**8, 2 * 10**8)
+    assert p.passes == 2 and p.bits1 + p.bits2 == 16    # avg build partition 3052 <= 15/16 * 4224
     p = P(10**9, 10**9)
-    assert p.passes == 2 and p.bits1 + p.bits2 == 18    # avg build partition 3815 <= 15/16 * 4224
+    assert (p.passes, p.bits1, p.bits2) == (2, 8, 8)    # 17-18 bits would re-read the input to count: 16 bits (one fused
+                                                        # histogram read) + the compact-table bucket join instead
     p = P(10**9, 10**9, O(2, 8, 8))
     assert (p.passes, p.bits1, p.bits2) == (2, 8, 8)    # BASELINE config 3 as named
     p = P(8 * 10**9, 8 * 10**9)

@@ -22,7 +22,7 @@ def test_cli_flags():
 @pytest.mark.gpu
 def test_reduced_run_prints_one_json_line():
     out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "2", "--warmup", "1",
-                          "--tuples", "4000000", "--cpu-sample", "200000"], capture_output=True, text=True, timeout=600)
+                          "--tuples", "4000000", "--cpu-sample", "200000", "--no-extras"], capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stderr[-2000:]
     lines = [l for l in out.stdout.splitlines() if l.strip()]
     assert len(lines) == 1
@@ -39,4 +39,6 @@ def test_reduced_run_prints_one_json_line():
     c = d["cpu_baseline"]
     for k in ("value", "unit", "cores", "kind", "sample"):
         assert k in c
-    assert c["kind"] in ("reference", "port")
+    assert c["kind"] in ("reference", "port") and c["cpu_model"] and c["cores"] in (1, 8)
+    if c["kind"] == "reference":                      # SURVEY §8d protocol: 8 threads and 1 thread, median of >= 3 runs each
+        assert set(c["tuples_per_s"]) == {"8_threads", "1_threads"} and all(len(v) >= 3 for v in c["runs_s"].values())

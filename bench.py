@@ -82,7 +82,7 @@ def cpu_baseline(sample_n, reps=3):
     return out
 
 
-def extras(eng, torch, dev, steps):
+def extras(eng, torch, dev, steps, which="all"):
     """N == 1 only, outside the timed region: the other BASELINE configs and the host-pointer drop-in, so that every
     number DESIGN.md quotes is on the driver's record.  Each leg verifies its pair set (count + checksum)."""
     import numpy as np
@@ -115,7 +115,7 @@ def extras(eng, torch, dev, steps):
     # config 4: 1B x 1B Zipf(0.9) foreign key, named 8+8 plan (= the automatic plan) and 9+9
     n = 1_000_000_000
     free, _ = eng.mem_info()
-    if free > 16 * n * 6.5:
+    if which == "all" and free > 16 * n * 6.5:
         R = torch.empty((n, 2), dtype=torch.int64, device=dev)
         S = torch.empty((n, 2), dtype=torch.int64, device=dev)
         out = torch.empty((n + 1024, 2), dtype=torch.int64, device=dev)
@@ -134,16 +134,15 @@ def extras(eng, torch, dev, steps):
     # the drop-in as the reference calls it: host AoS in, one malloc'd result page out (PCIe inclusive, pageable memory)
     from oracle import pyoracle                      # generators only (inputs); the join below is the HIP path
     o = pyoracle.Oracle()
-    n = 128_000_000
+    n = 128_000_000 if which == "all" else 16_000_000
     Rh, Sh = o.gen_R(n), o.gen_S_counter(n, n, 42)
     eng.join(Rh[:1_000_000], Sh[:1_000_000])
     secs = []
     for _ in range(3):
-        t0 = time.perf_counter()
-        cnt = eng.join_count_only_page(Rh, Sh)
-        secs.append(time.perf_counter() - t0)
+        cnt, dt_call = eng.join_count_only_page(Rh, Sh, timed=True)          # the C call alone (the page is freed outside)
+        secs.append(dt_call)
     sec = sorted(secs)[1]
-    res["end_to_end_rhj_join_128Mx128M"] = {"ms": sec * 1e3, "tuples_per_s": 2 * n / sec, "matches": cnt,
+    res[f"end_to_end_rhj_join_{n // 1_000_000}Mx{n // 1_000_000}M"] = {"ms": sec * 1e3, "tuples_per_s": 2 * n / sec, "matches": cnt,
                                             "pcie_GBps": (32.0 * n + 16.0 * cnt) / sec / 1e9, "runs_ms": [round(x * 1e3, 1) for x in secs],
                                             "note": "H2D of both inputs from pageable memory + kernels + D2H of the result page"}
     del Rh, Sh
@@ -180,9 +179,11 @@ def main():
     ap.add_argument("--tuples", type=int, default=1_000_000_000, help="rows of R and of S per GPU")
     ap.add_argument("--bits1", type=int, default=8)
     ap.add_argument("--bits2", type=int, default=8)
+    ap.add_argument("--passes", type=int, default=2, choices=[1, 2], help="1: single pass of --bits1 bits (BASELINE config 2)")
     ap.add_argument("--dist", choices=["uniform", "zipf"], default="uniform")
     ap.add_argument("--cpu-sample", type=int, default=64_000_000, help="rows per side of the CPU baseline sample (0 = skip)")
     ap.add_argument("--no-extras", action="store_true", help="skip the other BASELINE configs / end-to-end legs (N == 1)")
+    ap.add_argument("--extras", choices=["all", "small"], default="all", help="small: skip the 1B Zipf leg, 16M end-to-end")
     ap.add_argument("--no-verify", action="store_true")
     ap.add_argument("--no-auto", action="store_true", help="skip the extra (untimed-for-value) run under the automatic radix plan")
     args = ap.parse_args()
@@ -219,7 +220,7 @@ def main():
     eng.set_stream(stream.cuda_stream)
     n = args.tuples
     nglobal = n * world
-    opts = rhj.Opts(2, args.bits1, args.bits2)
+    opts = rhj.Opts(2, args.bits1, args.bits2) if args.passes == 2 else rhj.Opts(1, args.bits1, 0)
 
     # inputs resident in HBM, generated on device (SURVEY §8d generators; 16 B AoS tuples)
     R = torch.empty((n, 2), dtype=torch.int64, device=dev)
@@ -292,7 +293,7 @@ def main():
     if world == 1 and not args.no_auto:
         from radixhashjoin_amd.binding import plan as rhj_plan
         ap_ = rhj_plan(n, n)
-        if (ap_.passes, ap_.bits1, ap_.bits2) != (2, args.bits1, args.bits2):
+        if (ap_.passes, ap_.bits1, ap_.bits2) != (opts.passes, opts.bits1, opts.bits2):
             step(ap_)
             torch.cuda.synchronize()
             t1 = time.perf_counter()
@@ -312,12 +313,12 @@ def main():
         tuples_per_launch = n                                   # one launch scatters one relation shard once
         achieved = SCATTER_BYTES_PER_TUPLE * tuples_per_launch / (sc_ms * 1e-3) / 1e9 if sc_ms else 0.0
         part_ms = (kt["hist"][0] + kt["scan"][0] + kt["scatter"][0]) / args.steps
-        npass_tuples = 2 * 2 * n                                # 2 relations x 2 passes
+        npass_tuples = 2 * args.passes * n                      # 2 relations x passes
         traffic = None
         tpath = os.path.join(ROOT, "profiles", "traffic.json")
         if os.path.exists(tpath):
             tj = json.load(open(tpath))
-            if tj.get("tuples") == n and tj.get("bits") == [args.bits1, args.bits2]:
+            if tj.get("tuples") == n and tj.get("bits") == [args.bits1, args.bits2] and args.passes == 2:
                 traffic = tj.get("scatter_hbm_bytes_per_launch")
         line = {
             "metric": "join throughput (build+probe tuples/s)", "value": value, "unit": "tuples/s",
@@ -325,7 +326,8 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u64", "data": "synthetic",
             "verified": ok,
             "config": {"workload": f"{n} x {n} {args.dist} uint64 PK/FK radix hash join per GPU, "
-                                   f"2-pass ({args.bits1}+{args.bits2} bit) radix, inputs and pairs resident in HBM",
+                                   + (f"2-pass ({args.bits1}+{args.bits2} bit)" if args.passes == 2 else f"1-pass ({args.bits1} bit)")
+                                   + " radix, inputs and pairs resident in HBM",
                        "tuples_R_global": nglobal, "tuples_S_global": nglobal, "matches_last_step_rank0": cnt,
                        "exchange": "none (single GPU)" if world == 1 else "RCCL all-to-all by balanced owner class ranges"},
             "roofline": {"bound": "hbm", "kernel": "k_scatter_wc (line-aligned write-combining scatter-partition, one pass over one relation)",
@@ -346,7 +348,7 @@ def main():
             R = S = out = res = None                      # the headline inputs are done with: HBM back for the other configs
             eng.release_workspace()
             torch.cuda.empty_cache()
-            line["other_configs"] = extras(eng, torch, dev, args.steps)
+            line["other_configs"] = extras(eng, torch, dev, args.steps, args.extras)
         if world == 1 and args.cpu_sample > 0:
             line["cpu_baseline"] = cpu_baseline(args.cpu_sample)
             line["gpu_over_cpu"] = value / line["cpu_baseline"]["value"]

@@ -250,17 +250,21 @@ class Engine:
             assert n.value == 0
         return out
 
-    def join_count_only_page(self, R, S, opts=None):
+    def join_count_only_page(self, R, S, opts=None, timed=False):
         """rhj_join exactly as the C++ mirror calls it, the result page freed right away (what ~Result does): for
-        timing the drop-in without numpy's copy of the pairs"""
+        timing the drop-in without numpy's copy of the pairs.  timed=True also returns the seconds spent in the C call."""
+        import time
         R = np.ascontiguousarray(R, dtype=TUPLE)
         S = np.ascontiguousarray(S, dtype=TUPLE)
         page, n = _vp(), _u64()
-        self._chk(self.lib.rhj_join(self.ctx, R.ctypes.data, len(R), S.ctypes.data, len(S),
-                                    C.byref(opts) if opts is not None else None, C.byref(page), C.byref(n)))
+        t0 = time.perf_counter()
+        rc = self.lib.rhj_join(self.ctx, R.ctypes.data, len(R), S.ctypes.data, len(S),
+                               C.byref(opts) if opts is not None else None, C.byref(page), C.byref(n))
+        dt = time.perf_counter() - t0
+        self._chk(rc)
         if page.value:
             _libc_free(_vp(page.value))
-        return n.value
+        return (n.value, dt) if timed else n.value
 
     # ---- device-resident ------------------------------------------------------------------------
     def join_dev(self, d_R, nR, d_S, nS, d_out=None, capacity=0, opts=None, allow_overflow=False):

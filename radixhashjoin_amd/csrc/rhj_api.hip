@@ -5,6 +5,7 @@
 #include "../../include/rhj.h"
 #include "rhj_internal.h"
 
+#include <chrono>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -47,6 +48,8 @@ struct rhj_ctx {
     DevBuf seg0, unit_start, unit_hist, unit_base;
     DevBuf tasks, counters;            // counters: [0] u64 out_count, [1] u32 ntasks (+pad), [2] u64 checksum
     DevBuf out_pairs;                  // rhj_join's device result buffer
+    DevBuf small_out;                  // small-join path: 64-byte header {count} + pairs, fetched in one D2H
+    bool small_hdr_clean = false;      // the header has been zeroed behind the previous small join
     DevBuf hist_tmp, scan_tmp, hist2, grp_rng, unit_start2;
     // rhj_dev_alloc / rhj_dev_free keep released blocks for re-use (all work of a context is ordered on its one
     // stream, so a block may be handed out again while kernels that used it are still queued): a device-resident
@@ -63,6 +66,8 @@ struct rhj_ctx {
     u64 cur_nparts = 0, cur_nR = 0, cur_nS = 0;
     int cur_radix_bits = 0;
     u32 cur_probe_split = 0;
+    // pinned host landing zone of the small-join path: 64-byte header {count}, then up to 128 KiB of result pairs
+    unsigned char *h_land = nullptr;
     // tuning / test knobs (rhj_set_option)
     int opt_big_tables = -1;           // -1: by average build partition size, 0: never, 1: always use an oversized-partition kernel
     int opt_big_kernel = -1;           // -1: automatic, JK_BKT_BIG: never the compact-table kernel
@@ -218,7 +223,11 @@ int resolve_plan(u64 nR, u64 nS, const rhj_opts *in, rhj_opts *out)
         if (o.bits1 > 0) o.passes = o.bits2 > 0 ? 2 : 1;
         else {
             int bits = 0;
-            if (nb > (u64)BJ_CHUNK) bits = ilog2_ceil((nb + fit - 1) / fit);
+            const u64 np_ = nR < nS ? nS : nR;
+            // small joins stay unpartitioned (one launch, every probe tile re-builds the few table chunks): a partition
+            // pass costs ~6 launches per relation, more than such a join itself
+            const bool direct = nb <= DIRECT_MAX_BUILD && np_ <= DIRECT_MAX_PROBE;
+            if (nb > (u64)BJ_CHUNK && !direct) bits = ilog2_ceil((nb + fit - 1) / fit);
             if (bits == 0) o.passes = 0;
             else if (bits <= 9) { o.passes = 1; o.bits1 = bits; }
             else {
@@ -373,6 +382,13 @@ int partition_relation(rhj_ctx *ctx, const void *d_in, u64 n, int passes, int b1
     return run_pass(ctx, ctx->part_tmp.p, d_out, n, (const u64 *)ctx->ps_1.p, 1u << b1, b1, b2, d_ps);
 }
 
+// Small unpartitioned joins run as ONE launch without a task list (k_join_bkt DIRECT).
+bool is_direct(const rhj_ctx *ctx, u64 nparts, u64 nR, u64 nS)
+{
+    return nparts == 1 && ctx->opt_big_tables != 1 && (nR < nS ? nR : nS) <= DIRECT_MAX_BUILD &&
+           (nR < nS ? nS : nR) <= DIRECT_MAX_PROBE;
+}
+
 // Partition phase of a join: leaves ctx->cur_* describing partitioned R and S.
 int partition_phase(rhj_ctx *ctx, const void *d_R, u64 nR, const void *d_S, u64 nS, const rhj_opts &plan)
 {
@@ -385,7 +401,7 @@ int partition_phase(rhj_ctx *ctx, const void *d_R, u64 nR, const void *d_S, u64 
     if (plan.passes == 0) {
         RHJCHK(ensure(ctx, ctx->ps_R, 64));
         RHJCHK(ensure(ctx, ctx->ps_S, 64));
-        {
+        if (!is_direct(ctx, 1, nR, nS)) {                               // boundaries {0, n} for the task list (the direct launch needs none)
             Span s(ctx, RHJ_K_AUX);
             launch_init_single_segment(ctx->stream, nR, PART_TILE, (u64 *)ctx->ps_R.p, (u32 *)((u64 *)ctx->ps_R.p + 4));
             launch_init_single_segment(ctx->stream, nS, PART_TILE, (u64 *)ctx->ps_S.p, (u32 *)((u64 *)ctx->ps_S.p + 4));
@@ -439,15 +455,20 @@ int join_phase_on(rhj_ctx *ctx, const void *d_Rp, const u64 *d_psR, u64 nR, cons
         Span s(ctx, RHJ_K_AUX);
         HIPCHK(ctx, hipMemsetAsync(ctx->counters.p, 0, 64, ctx->stream));
     }
-    {
-        Span s(ctx, RHJ_K_TASKS);
-        launch_make_tasks(ctx->stream, d_psR, d_psS, nparts, probe_split, (JoinTask *)ctx->tasks.p, d_ntasks, max_tasks,
-                          d_count + 2, kind);                       // counters[2..3]: largest partition of R, S
-    }
-    {
-        Span s(ctx, RHJ_K_JOIN);
-        launch_join(ctx->stream, d_Rp, d_psR, d_Sp, d_psS, (const JoinTask *)ctx->tasks.p, d_ntasks, max_tasks,
-                    radix_bits, d_out, d_out ? cap : 0, d_count, kind);
+    if (is_direct(ctx, nparts, nR, nS)) {
+        Span s(ctx, RHJ_K_JOIN);                                     // small unpartitioned join: one launch, no task list
+        launch_join_direct(ctx->stream, d_Rp, nR, d_Sp, nS, d_out, d_out ? cap : 0, d_count);
+    } else {
+        {
+            Span s(ctx, RHJ_K_TASKS);
+            launch_make_tasks(ctx->stream, d_psR, d_psS, nparts, probe_split, (JoinTask *)ctx->tasks.p, d_ntasks, max_tasks,
+                              d_count + 2, kind);                   // counters[2..3]: largest partition of R, S
+        }
+        {
+            Span s(ctx, RHJ_K_JOIN);
+            launch_join(ctx->stream, d_Rp, d_psR, d_Sp, d_psS, (const JoinTask *)ctx->tasks.p, d_ntasks, max_tasks,
+                        radix_bits, d_out, d_out ? cap : 0, d_count, kind);
+        }
     }
     RHJCHK(check_launch(ctx, "join phase"));
     u64 host[6] = {0, 0, 0, 0, 0, 0};          // count, ntasks, max |R_k|, max |S_k|, (checksum scratch), oversized build side
@@ -538,15 +559,17 @@ int rhj_release_workspace(rhj_ctx *ctx)
     (void)hipStreamSynchronize(ctx->stream);
     DevBuf *all[] = {&ctx->in_R, &ctx->in_S, &ctx->part_R, &ctx->part_S, &ctx->part_tmp, &ctx->ps_R, &ctx->ps_S,
                      &ctx->ps_1, &ctx->seg0, &ctx->unit_start, &ctx->unit_hist, &ctx->unit_base, &ctx->tasks,
-                     &ctx->counters, &ctx->out_pairs, &ctx->hist_tmp, &ctx->scan_tmp, &ctx->hist2,
+                     &ctx->counters, &ctx->out_pairs, &ctx->small_out, &ctx->hist_tmp, &ctx->scan_tmp, &ctx->hist2,
                      &ctx->grp_rng, &ctx->unit_start2};
     for (DevBuf *b : all) release(*b);
+    ctx->small_hdr_clean = false;
     for (auto &b : ctx->free_blocks) {
         { std::lock_guard<std::mutex> lk(g_pool_sizes_mu); g_pool_sizes.erase(b.first); }
         (void)hipFree(b.first);
     }
     ctx->free_blocks.clear();
     ctx->free_bytes = 0;
+    if (ctx->h_land) { (void)hipHostFree(ctx->h_land); ctx->h_land = nullptr; }
     for (int i = 0; i < 2; i++) {
         if (ctx->stage[i]) { (void)hipHostFree(ctx->stage[i]); ctx->stage[i] = nullptr; }
         if (ctx->stage_ev[i]) { (void)hipEventDestroy(ctx->stage_ev[i]); ctx->stage_ev[i] = nullptr; }
@@ -683,6 +706,84 @@ struct PagePrefault {
 
 }  // namespace
 
+namespace {
+
+// rhj_join for small inputs (the 94 joins of small.work are <= 43 K tuples).  Every asynchronous operation
+// costs 5-10 us of latency on this platform whatever its size (measured: 2 H2D + memset + kernel + 2 D2H = 48 us for a
+// 3754 x 14368 join whose kernel runs ~10 us), so the sequence is cut to FOUR operations and one host synchronisation:
+//   H2D R, H2D S, ONE kernel (k_join_bkt DIRECT), ONE D2H of {result count | pairs} -- the count lives in a 64-byte
+//   header in front of the pairs in HBM, and the optimistic number of pairs (a foreign-key join yields about
+//   max(|R|,|S|); at most 1 MiB) travels with it into pinned memory, from where one memcpy fills the exact-size page;
+//   whatever a larger result has beyond that is fetched from HBM straight into the page.
+// The header is zeroed for the NEXT call after this one has read it (off the critical path).
+constexpr size_t LAND_BYTES = (size_t)1 << 20;
+
+int join_small_host(rhj_ctx *ctx, const rhj_tuple *R, u64 nR, const rhj_tuple *S, u64 nS, void **out_page, u64 *out_count)
+{
+    static const bool trace = getenv("RHJ_TRACE_SMALL") != nullptr;       // tuning aid: host-side timeline on stderr
+    auto now = [] { return std::chrono::steady_clock::now(); };
+    auto us = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) {
+        return std::chrono::duration<double, std::micro>(b - a).count();
+    };
+    const auto t0 = now();
+    const u64 guess = (nR > nS ? nR : nS) + 1024;
+    RHJCHK(ensure(ctx, ctx->in_R, (size_t)nR * 16));
+    RHJCHK(ensure(ctx, ctx->in_S, (size_t)nS * 16));
+    if (!ctx->h_land) HIPCHK(ctx, hipHostMalloc((void **)&ctx->h_land, 64 + LAND_BYTES, hipHostMallocDefault));
+    if (ctx->small_out.cap < 64 + (size_t)guess * 16) {
+        RHJCHK(ensure(ctx, ctx->small_out, 64 + (size_t)guess * 16));
+        ctx->small_hdr_clean = false;
+    }
+    HIPCHK(ctx, hipMemcpyAsync(ctx->in_R.p, R, (size_t)nR * 16, hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(ctx, hipMemcpyAsync(ctx->in_S.p, S, (size_t)nS * 16, hipMemcpyHostToDevice, ctx->stream));
+    ctx->last.passes = 0;
+    u64 count = 0, landed = 0;
+    for (int attempt = 0; attempt < 2; attempt++) {
+        unsigned char *d_hdr = (unsigned char *)ctx->small_out.p;
+        const u64 dcap = (ctx->small_out.cap - 64) / 16;
+        if (!ctx->small_hdr_clean) HIPCHK(ctx, hipMemsetAsync(d_hdr, 0, 64, ctx->stream));
+        ctx->small_hdr_clean = false;
+        {
+            Span s(ctx, RHJ_K_JOIN);
+            launch_join_direct(ctx->stream, ctx->in_R.p, nR, ctx->in_S.p, nS, d_hdr + 64, dcap, (u64 *)d_hdr);
+        }
+        RHJCHK(check_launch(ctx, "direct join"));
+        landed = attempt == 0 ? guess : dcap;                             // pairs that travel with the count
+        if (landed > dcap) landed = dcap;
+        if (landed * 16 > LAND_BYTES) landed = LAND_BYTES / 16;
+        const auto t1 = now();
+        HIPCHK(ctx, hipMemcpyAsync(ctx->h_land, d_hdr, 64 + (size_t)landed * 16, hipMemcpyDeviceToHost, ctx->stream));
+        HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+        count = *(const u64 *)ctx->h_land;
+        if (trace) fprintf(stderr, "[small join %llu x %llu -> %llu] enqueue %.1f  d2h+sync %.1f us\n", (unsigned long long)nR,
+                           (unsigned long long)nS, (unsigned long long)count, us(t0, t1), us(t1, now()));
+        if (count <= dcap) break;                                         // every pair is in HBM
+        if (attempt == 1) return fail(ctx, RHJ_E_HIP, "result count changed between join phases");
+        RHJCHK(ensure(ctx, ctx->small_out, 64 + (size_t)count * 16));     // more pairs than the buffer holds: exact size known now
+    }
+    unsigned char *page = nullptr;
+    if (count) {
+        page = (unsigned char *)malloc(8 + (size_t)count * 16);
+        if (!page) return fail(ctx, RHJ_E_NOMEM, "malloc of the result page failed");
+        memset(page, 0, 8);                                               // bucket_info::next = nullptr (Result.h:14-17)
+        const u64 got = count < landed ? count : landed;
+        memcpy(page + 8, ctx->h_land + 64, (size_t)got * 16);
+        if (count > got) {                                                // the rest straight from HBM into the page
+            hipError_t e = hipMemcpyAsync(page + 8 + got * 16, (const unsigned char *)ctx->small_out.p + 64 + got * 16,
+                                          (size_t)(count - got) * 16, hipMemcpyDeviceToHost, ctx->stream);
+            if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+            if (e != hipSuccess) { free(page); return fail(ctx, RHJ_E_HIP, std::string("result copy: ") + hipGetErrorString(e)); }
+        }
+    }
+    // header of the next small join: zeroed behind this one
+    if (hipMemsetAsync(ctx->small_out.p, 0, 64, ctx->stream) == hipSuccess) ctx->small_hdr_clean = true;
+    *out_page = page;                                                     // nullptr when nothing matched (Result::isEmpty)
+    *out_count = count;
+    return RHJ_OK;
+}
+
+}  // namespace
+
 int rhj_join(rhj_ctx *ctx, const rhj_tuple *R, uint64_t nR, const rhj_tuple *S, uint64_t nS,
              const rhj_opts *opts, void **out_page, uint64_t *out_count)
 {
@@ -695,6 +796,7 @@ int rhj_join(rhj_ctx *ctx, const rhj_tuple *R, uint64_t nR, const rhj_tuple *S, 
     if (!R || !S) return fail(ctx, RHJ_E_INVALID, "null input relation");
     rhj_opts plan;
     if (resolve_plan(nR, nS, opts, &plan) != RHJ_OK) return fail(ctx, RHJ_E_INVALID, "bad rhj_opts");
+    if (plan.passes == 0 && is_direct(ctx, 1, nR, nS)) return join_small_host(ctx, R, nR, S, nS, out_page, (u64 *)out_count);
     // optimistic capacity: a foreign-key join yields about max(|R|,|S|) pairs; the count is exact
     // either way, and an overflow only repeats the join phase (partitions stay in the workspace)
     u64 cap = (nR > nS ? nR : nS) + 1024;

@@ -24,6 +24,9 @@ constexpr int BJ_BUCKET_BITS = 11;                // 2048 hash buckets (offsets:
 constexpr int BJ_EPT = 8;                         // probe tuples per thread per tile
 constexpr int BJ_TILE = BJ_THREADS * BJ_EPT;      // 4096
 constexpr int BJ_FIT = BJ_CHUNK * 15 / 16;        // plan: average build partition <= 3960 tuples
+// small joins run unpartitioned in one launch (k_join_bkt DIRECT): every 4096-tuple probe tile re-builds the table chunks
+constexpr u64 DIRECT_MAX_BUILD = 12ull * BJ_CHUNK; // build side of at most 12 table chunks ...
+constexpr u64 DIRECT_MAX_PROBE = 131072;          // ... probed by at most 32 workgroups
 
 struct JoinTask {           // one workgroup's work: probe range [pbeg, pbeg+plen) against build range [bbeg, bbeg+blen)
     u64 pbeg;               // absolute index into the probe-side array
@@ -59,6 +62,8 @@ void launch_make_tasks(hipStream_t st, const u64 *d_startR, const u64 *d_startS,
 void launch_join(hipStream_t st, const void *d_R, const u64 *d_startR, const void *d_S, const u64 *d_startS,
                  const JoinTask *d_tasks, const u32 *d_ntasks, u32 grid, int radix_bits,
                  void *d_out, u64 out_capacity, u64 *d_out_count, int kind);
+void launch_join_direct(hipStream_t st, const void *d_R, u64 nR, const void *d_S, u64 nS, void *d_out, u64 out_capacity,
+                        u64 *d_out_count);
 void launch_checksum(hipStream_t st, const void *d_pairs, u64 n, u64 *d_sum);
 void launch_generate(hipStream_t st, int kind, void *d_out, u64 n, u64 row0, u64 D, u64 seed, double theta);
 void launch_expected_pkfk(hipStream_t st, const void *d_S, u64 n, u64 *d_sum);

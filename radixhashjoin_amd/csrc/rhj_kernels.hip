@@ -818,11 +818,16 @@ __device__ __forceinline__ u32 bj_bucket(u64 v, int radix_bits)
 //   <1024, 8448, 12, 4>  one workgroup per CU (152 KiB LDS): used when the AVERAGE build partition exceeds 4224 tuples
 //                        (explicit plans such as 8+8 bits at 10^9 tuples): half as many build chunks, so half as
 //                        many re-probes of the probe side
-template <int THREADS, int CHUNK, int BBITS, int EPT>
+// DIRECT: no task list -- the inputs are ONE unpartitioned pair of relations and workgroup b probes tuples
+// [b * dsplit, (b+1) * dsplit) of the probe side against the whole build side (small joins: the launch sequence
+// k_part_max / k_make_tasks / task-list read would cost more than the join itself).
+struct DirectJoin { u32 nb, np, build_is_S, split; };
+
+template <int THREADS, int CHUNK, int BBITS, int EPT, bool DIRECT>
 __global__ void __launch_bounds__(THREADS, 4)
 k_join_bkt(const Tup *__restrict__ R, const Tup *__restrict__ S, const JoinTask *__restrict__ tasks,
            const u32 *__restrict__ ntasks, int radix_bits, Pair *__restrict__ out, u64 out_capacity,
-           u64 *__restrict__ out_count)
+           u64 *__restrict__ out_count, DirectJoin dj)
 {
     constexpr int NB = 1 << BBITS;
     constexpr int NW = THREADS / 64;
@@ -837,9 +842,18 @@ k_join_bkt(const Tup *__restrict__ R, const Tup *__restrict__ S, const JoinTask 
     u32 *wsum = wtot + 64;                                                   // NW scan scratch
     u64 *gres = reinterpret_cast<u64 *>(wsum + NW);                          // 1
 
-    const u32 nt = *ntasks;
-    if (blockIdx.x >= nt) return;
-    const JoinTask task = tasks[blockIdx.x];
+    JoinTask task;
+    if (DIRECT) {
+        task.pbeg = (u64)blockIdx.x * dj.split;
+        task.plen = dj.np - (u32)task.pbeg < dj.split ? dj.np - (u32)task.pbeg : dj.split;
+        task.bbeg = 0;
+        task.blen = dj.nb;
+        task.build_is_S = dj.build_is_S;
+    } else {
+        const u32 nt = *ntasks;
+        if (blockIdx.x >= nt) return;
+        task = tasks[blockIdx.x];
+    }
     const bool build_is_S = task.build_is_S != 0;
     const Tup *__restrict__ B = (build_is_S ? S : R) + task.bbeg;
     const Tup *__restrict__ P = (build_is_S ? R : S) + task.pbeg;
@@ -1493,10 +1507,13 @@ static void allow_big_lds()
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)wc_lds_bytes(WC_MAX_BITS, WC_THREADS));
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_scatter_wc<WC_THREADS_SMALL>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)wc_lds_bytes(WC_MAX_BITS, WC_THREADS_SMALL));
-    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_join_bkt<BJ_THREADS, BJ_CHUNK, BJ_BUCKET_BITS, BJ_EPT>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_join_bkt<BJ_THREADS, BJ_CHUNK, BJ_BUCKET_BITS, BJ_EPT, false>),
                               hipFuncAttributeMaxDynamicSharedMemorySize,
                               (int)bj_lds_bytes(BJ_THREADS, BJ_CHUNK, BJ_BUCKET_BITS));
-    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_join_bkt<BJ2_THREADS, BJ2_CHUNK, BJ2_BUCKET_BITS, BJ2_EPT>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_join_bkt<BJ_THREADS, BJ_CHUNK, BJ_BUCKET_BITS, BJ_EPT, true>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize,
+                              (int)bj_lds_bytes(BJ_THREADS, BJ_CHUNK, BJ_BUCKET_BITS));
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_join_bkt<BJ2_THREADS, BJ2_CHUNK, BJ2_BUCKET_BITS, BJ2_EPT, false>),
                               hipFuncAttributeMaxDynamicSharedMemorySize,
                               (int)bj_lds_bytes(BJ2_THREADS, BJ2_CHUNK, BJ2_BUCKET_BITS));
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_join_ct<CT_THREADS, CT_CHUNK, CT_BUCKET_BITS, CT_EPT, false>),
@@ -1629,15 +1646,15 @@ void launch_join(hipStream_t st, const void *d_R, const u64 *d_startR, const voi
     if (grid == 0) return;
     allow_big_lds();
     if (kind == JK_BKT) {
-        hipLaunchKernelGGL((k_join_bkt<BJ_THREADS, BJ_CHUNK, BJ_BUCKET_BITS, BJ_EPT>), dim3(grid), dim3(BJ_THREADS),
+        hipLaunchKernelGGL((k_join_bkt<BJ_THREADS, BJ_CHUNK, BJ_BUCKET_BITS, BJ_EPT, false>), dim3(grid), dim3(BJ_THREADS),
                            bj_lds_bytes(BJ_THREADS, BJ_CHUNK, BJ_BUCKET_BITS), st, (const Tup *)d_R, (const Tup *)d_S,
-                           d_tasks, d_ntasks, radix_bits, (Pair *)d_out, out_capacity, d_out_count);
+                           d_tasks, d_ntasks, radix_bits, (Pair *)d_out, out_capacity, d_out_count, DirectJoin{});
         return;
     }
     if (kind == JK_BKT_BIG) {
-        hipLaunchKernelGGL((k_join_bkt<BJ2_THREADS, BJ2_CHUNK, BJ2_BUCKET_BITS, BJ2_EPT>), dim3(grid), dim3(BJ2_THREADS),
+        hipLaunchKernelGGL((k_join_bkt<BJ2_THREADS, BJ2_CHUNK, BJ2_BUCKET_BITS, BJ2_EPT, false>), dim3(grid), dim3(BJ2_THREADS),
                            bj_lds_bytes(BJ2_THREADS, BJ2_CHUNK, BJ2_BUCKET_BITS), st, (const Tup *)d_R, (const Tup *)d_S,
-                           d_tasks, d_ntasks, radix_bits, (Pair *)d_out, out_capacity, d_out_count);
+                           d_tasks, d_ntasks, radix_bits, (Pair *)d_out, out_capacity, d_out_count, DirectJoin{});
         return;
     }
     static const bool want_stamps = getenv("RHJ_CT_STAMPS") != nullptr;
@@ -1674,6 +1691,22 @@ void launch_join(hipStream_t st, const void *d_R, const u64 *d_startR, const voi
     hipLaunchKernelGGL((k_join_ct<CT_THREADS, CT_CHUNK, CT_BUCKET_BITS, CT_EPT, false>), dim3(grid), dim3(CT_THREADS),
                        ct_lds_bytes(), st, (const Tup *)d_R, (const Tup *)d_S, d_tasks, d_ntasks, radix_bits,
                        (Pair *)d_out, out_capacity, d_out_count, (u64 *)nullptr, 0u);
+}
+
+// Unpartitioned join of two small relations in ONE launch: build side = S when nR >= nS (JobScheduler.cpp:187).
+void launch_join_direct(hipStream_t st, const void *d_R, u64 nR, const void *d_S, u64 nS, void *d_out, u64 out_capacity,
+                        u64 *d_out_count)
+{
+    allow_big_lds();
+    DirectJoin dj;
+    dj.build_is_S = nR >= nS ? 1u : 0u;
+    dj.nb = (u32)(dj.build_is_S ? nS : nR);
+    dj.np = (u32)(dj.build_is_S ? nR : nS);
+    dj.split = (u32)BJ_TILE;
+    const u32 grid = (dj.np + dj.split - 1) / dj.split;
+    hipLaunchKernelGGL((k_join_bkt<BJ_THREADS, BJ_CHUNK, BJ_BUCKET_BITS, BJ_EPT, true>), dim3(grid), dim3(BJ_THREADS),
+                       bj_lds_bytes(BJ_THREADS, BJ_CHUNK, BJ_BUCKET_BITS), st, (const Tup *)d_R, (const Tup *)d_S,
+                       (const JoinTask *)nullptr, (const u32 *)nullptr, 0, (Pair *)d_out, out_capacity, d_out_count, dj);
 }
 
 static unsigned stream_grid(u64 n)

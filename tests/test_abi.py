@@ -40,6 +40,8 @@ def test_plan_auto():
     assert P(1, 1561).passes == 0                       # tiny build side: no partitioning (one LDS table)
     assert P(4224, 10**6).passes == 0                   # BJ_CHUNK tuples fit one LDS table
     assert P(4225, 10**6).passes == 1
+    assert P(43131, 42987).passes == 0                  # small joins (small.work sizes): unpartitioned, one launch
+    assert P(50689, 60000).passes == 1 and P(20000, 131073).passes == 1
     p = P(10**6, 10**6)
     assert (p.passes, p.bits1, p.bits2) == (1, 8, 0)    # BASELINE config 2: 1M x 1M, 8-bit, single pass
     p = P(2 * 10**8, 2 * 10**8)

@@ -1087,7 +1087,7 @@ k_join_ct(const Tup *__restrict__ R, const Tup *__restrict__ S, const JoinTask *
     constexpr int NB = 1 << BBITS;
     constexpr int NW = THREADS / 64;
     constexpr int BPT = (CHUNK + THREADS - 1) / THREADS;            // build tuples per thread
-    constexpr int BB = 7;                                           // build loads in flight per lane
+    constexpr int BB = BPT;                                         // build loads in flight per lane: the whole build side
     constexpr int WPT = NB / 2 / THREADS;                           // packed counter words per thread in the scan
     constexpr int PT = CT_PT, NT = EPT / PT, DEPTH = CT_DEPTH;      // probe tile: PT slots; ring of DEPTH tiles
     static_assert(EPT % PT == 0 && EPT <= 32 && NB % (2 * THREADS) == 0 && CHUNK < (int)CT_NONE && BPT % BB == 0 && NW <= 64,
@@ -1100,6 +1100,9 @@ k_join_ct(const Tup *__restrict__ R, const Tup *__restrict__ S, const JoinTask *
     u32 *wsum = off32 + NB / 2 + 2;                                          // NW scan scratch
     u32 *wtot = wsum + NW;                                                   // NW match totals
     u64 *gres = reinterpret_cast<u64 *>(wtot + NW);                          // 1
+    u64 *dummy = gres + 1;                                                   // target of the LDS writes of out-of-range slots:
+    // range checks select an address instead of branching, so that the reads / atomics of a whole batch are in
+    // flight together (a branch per slot costs one exposed LDS round trip each: measured 35 of them per build phase)
 
     const u32 nt = *ntasks;
     if (blockIdx.x >= nt) return;
@@ -1137,11 +1140,8 @@ k_join_ct(const Tup *__restrict__ R, const Tup *__restrict__ S, const JoinTask *
 #pragma unroll
             for (int k = k0; k < k0 + BB; k++) {
                 const u64 key = bt[k - k0].payload >> rb;
-                kr[k] = key << 16;
-                if (k < nvb) {
-                    const u32 h = ct_bucket<BBITS>(key), sh = (h & 1u) * 16u;
-                    kr[k] |= (atomicAdd(&off32[h >> 1], 1u << sh) >> sh) & 0xFFFFu;
-                }
+                const u32 h = k < nvb ? ct_bucket<BBITS>(key) : (u32)NB + 2u, sh = (h & 1u) * 16u;   // NB + 2: a padding word
+                kr[k] = (key << 16) | ((atomicAdd(&off32[h >> 1], 1u << sh) >> sh) & 0xFFFFu);
             }
         }
         stamp();                                                             // 1: build side loaded and counted
@@ -1168,12 +1168,9 @@ k_join_ct(const Tup *__restrict__ R, const Tup *__restrict__ S, const JoinTask *
             const int nvp = nc > (u32)tp ? (int)((nc - (u32)tp + THREADS - 1) / THREADS) : 0;
 #pragma unroll
             for (int k = 0; k < BPT; k++) {
-                u32 pos = 0;
-                if (k < nvp) {
-                    const u64 key = kr[k] >> 16;
-                    pos = off16[ct_bucket<BBITS>(key)] + ((u32)kr[k] & 0xFFFFu);
-                    ent[pos] = (key << 16) | (u64)((u32)k * THREADS + tp);
-                }
+                const u64 key = kr[k] >> 16;
+                const u32 pos = off16[ct_bucket<BBITS>(key)] + ((u32)kr[k] & 0xFFFFu);
+                *(k < nvp ? &ent[pos] : dummy) = (key << 16) | (u64)((u32)k * THREADS + tp);
                 if (k & 1) ppos[k >> 1] |= pos << 16; else ppos[k >> 1] = pos;
             }
         }
@@ -1203,8 +1200,8 @@ k_join_ct(const Tup *__restrict__ R, const Tup *__restrict__ S, const JoinTask *
                 const u64 key = ring[t % DEPTH][s].payload >> rb;
                 const u32 h = ct_bucket<BBITS>(key);
                 khi[s] = (u32)(key >> 16); klo[s] = (u32)key << 16;
-                lo[s] = 0; len[s] = 0; m[s] = 0;
-                if (k < nv) { lo[s] = off16[h]; len[s] = off16[h + 1] - lo[s]; }
+                lo[s] = off16[h]; m[s] = 0;
+                len[s] = k < nv ? off16[h + 1] - lo[s] : 0u;
                 maxlen = len[s] > maxlen ? len[s] : maxlen;
             }
             if (t + DEPTH < NT) {                                            // the slot is free: next tile on its way
@@ -1337,7 +1334,7 @@ k_join_ct(const Tup *__restrict__ R, const Tup *__restrict__ S, const JoinTask *
             const int nvd = nc > (u32)td ? (int)((nc - (u32)td + THREADS - 1) / THREADS) : 0;
 #pragma unroll
             for (int k = 0; k < BPT; k++)
-                if (k < nvd) rid[(k & 1) ? (ppos[k >> 1] >> 16) : (ppos[k >> 1] & 0xFFFFu)] = brid[k];   // table order
+                *(k < nvd ? &rid[(k & 1) ? (ppos[k >> 1] >> 16) : (ppos[k >> 1] & 0xFFFFu)] : dummy) = brid[k];   // table order
         }
         stamp();                                                             // 7: rowIDs in LDS
         const u32 mine = lane < NW ? wtot[lane] : 0u;
@@ -1494,7 +1491,7 @@ static int current_device_slot()
 
 static size_t ct_lds_bytes()
 {
-    return (size_t)CT_CHUNK * 8 + ((size_t)(1 << CT_BUCKET_BITS) / 2 + 2 + 2 * (CT_THREADS / 64)) * 4 + 16;
+    return (size_t)CT_CHUNK * 8 + ((size_t)(1 << CT_BUCKET_BITS) / 2 + 2 + 2 * (CT_THREADS / 64)) * 4 + 24;
 }
 
 static void allow_big_lds()

@@ -323,12 +323,11 @@ void Query::run_joins(JobScheduler &js, vector<relList> &relations, FilteredRows
     if (filtered_out) return;
     for (proj_info &p : proj) {
         const uint64_t *col = relations[table[p.table]].values[p.column];
+        // column_proj (Query.cpp:66-74) over intermediate[p.table]: an alias that is not part of the intermediate
+        // (never joined, or dropped when a later join linked two new aliases, intermediate.cpp:147-162) sums to 0,
+        // exactly as the reference prints it (tests/golden/edge, generated by the real reference)
         uint64_t sum = 0;
-        if (intermediate[p.table].empty()) {                            // alias never joined: sum over its filtered rows
-            for (uint64_t rowid : filtered[p.table]) sum += col[rowid];
-        } else {
-            for (uint64_t rowid : intermediate[p.table]) sum += col[rowid];
-        }
+        for (uint64_t rowid : intermediate[p.table]) sum += col[rowid];
         p.sum = sum;
     }
 }

@@ -181,9 +181,10 @@ void Query::execute_device(JobScheduler &js, std::vector<relList> &relations)
     // ---- SUM projections (Query.cpp:66-74,198-200) -------------------------------------------
     for (proj_info &p : proj) {
         const uint64_t *col = device_column(ctx, relations[table[p.table]], p.column);
+        // an alias that is not part of the intermediate (never joined, or dropped when a later join linked two new
+        // aliases) sums to 0, as in the reference (Query.cpp:198-200 over an empty intermediate[p.table])
         uint64_t sum = 0;
         if (!inter[p.table].empty()) OK(ctx, rhj_sum_gather(ctx, col, inter[p.table].p, T, &sum));
-        else OK(ctx, rhj_sum_gather(ctx, col, rows[p.table].ptr(), rows[p.table].n, &sum));
         p.sum = sum;
     }
 }

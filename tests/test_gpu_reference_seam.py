@@ -42,3 +42,17 @@ def test_reference_code_drives_gpu_join(tmp_path, small_joins):
     want = collections.Counter((c["nR"], c["nS"], c["count"]) for c in meta)
     got = collections.Counter(tuple(int(x) for x in line.split()) for line in open(tmp_path / "join_seam.log"))
     assert sum(got.values()) == 94 and got == want
+
+
+def test_reference_code_drives_gpu_join_edge_queries():
+    """the same three binaries on the edge-case queries of tests/golden/edge (expected lines from the CPU reference)"""
+    paths = {b: os.path.join(ROOT, "oracle", "_ref", b) for b in BINARIES}
+    if any(not os.path.exists(p) for p in paths.values()):
+        pytest.skip("bindings not built (needs the reference checkout at build time)")
+    edge = os.path.join(GOLD, "edge")
+    stdin = open(os.path.join(edge, "edge.init"), "rb").read() + open(os.path.join(edge, "edge.work"), "rb").read()
+    expected = open(os.path.join(edge, "edge.result"), "rb").read()
+    for b, p in paths.items():
+        r = subprocess.run([p], input=stdin, cwd=GOLD, capture_output=True, timeout=600)
+        assert r.returncode == 0, (b, r.stderr[-2000:])
+        assert r.stdout == expected, b

@@ -39,3 +39,17 @@ def test_small_work_device_resident_queries(tmp_path):
     filters, position-carrying join inputs, gathered intermediates, device SUMs): same 50 lines"""
     out, _ = run_small(tmp_path, mode="device")
     assert out == open(os.path.join(GOLD, "small", "small.result"), "rb").read()
+
+
+@pytest.mark.parametrize("mode", ["host", "device"])
+def test_edge_queries_match_the_reference(mode):
+    """corners of Query::run_joins that small.work never reaches: a projected alias that is never joined (sums to 0,
+    Query.cpp:198-200 over an empty intermediate), two disconnected joins (the second drops the older columns,
+    intermediate.cpp:147-162), the a-b / c-d / b-c order, a predicate between two aliases already joined.  Expected
+    lines were printed by the REAL reference (tests/golden/make_edge.py); same-alias predicates are parity-unpinned (the
+    reference segfaults on them)."""
+    edge = os.path.join(GOLD, "edge")
+    stdin = open(os.path.join(edge, "edge.init"), "rb").read() + open(os.path.join(edge, "edge.work"), "rb").read()
+    env = dict(os.environ, RHJ_QUERY_MODE=mode)
+    out = subprocess.run([JOIN], input=stdin, cwd=GOLD, env=env, capture_output=True, timeout=600, check=True).stdout
+    assert out == open(os.path.join(edge, "edge.result"), "rb").read()

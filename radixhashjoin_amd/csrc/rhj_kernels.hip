@@ -307,12 +307,14 @@ k_scan_units(const u64 *__restrict__ seg_start, const u32 *__restrict__ unit_sta
 
 
 // K2 for ONE long segment (pass 1: up to ~2048 units): the same result as k_scan_units, computed by
-// SCAN_SLICES workgroups in three short launches instead of one workgroup walking every unit.
+// up to SCAN_SLICES workgroups in three short launches instead of one workgroup walking every unit.  The number of
+// slices is ~sqrt(units): the middle kernel walks the slices serially (one dependent load each), the outer two walk
+// the units of a slice (measured at 245 units: 64 slices 8.9 us for the middle kernel alone).
 constexpr u32 SCAN_SLICES = 64;
 
-__device__ __forceinline__ void slice_range(u32 nu, u32 k, u32 &ub, u32 &ue)
+__device__ __forceinline__ void slice_range(u32 nu, u32 nsl, u32 k, u32 &ub, u32 &ue)
 {
-    const u32 per = (nu + SCAN_SLICES - 1) / SCAN_SLICES;
+    const u32 per = (nu + nsl - 1) / nsl;
     ub = k * per < nu ? k * per : nu;
     ue = (k + 1) * per < nu ? (k + 1) * per : nu;
 }
@@ -323,7 +325,7 @@ k_scan1_partial(const u32 *__restrict__ unit_start, int bits, const u32 *__restr
 {
     const u32 nbins = 1u << bits, nu = unit_start[1];
     u32 ub, ue;
-    slice_range(nu, blockIdx.x, ub, ue);
+    slice_range(nu, gridDim.x, blockIdx.x, ub, ue);
     for (u32 d = threadIdx.x; d < nbins; d += 1024) {
         u64 sum = 0;
         for (u32 u = ub; u < ue; u++) sum += unit_hist[(u64)u * nbins + d];
@@ -333,14 +335,14 @@ k_scan1_partial(const u32 *__restrict__ unit_start, int bits, const u32 *__restr
 
 // partial[k][d] <- part_start[d] + sum_{k'<k} partial[k'][d];  part_start[d] = exclusive prefix of the digit totals
 __global__ void __launch_bounds__(1024)
-k_scan1_mid(int bits, u64 *__restrict__ partial, u64 *__restrict__ part_start, u64 n_total)
+k_scan1_mid(int bits, u32 nsl, u64 *__restrict__ partial, u64 *__restrict__ part_start, u64 n_total)
 {
     __shared__ u64 wtot[16];
     const u32 nbins = 1u << bits;                         // <= 1024
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const u32 d = threadIdx.x;
     u64 tot = 0;
-    if (d < nbins) for (u32 k = 0; k < SCAN_SLICES; k++) tot += partial[(u64)k * nbins + d];
+    if (d < nbins) for (u32 k = 0; k < nsl; k++) tot += partial[(u64)k * nbins + d];
     u64 inc = tot;
 #pragma unroll
     for (int off = 1; off < 64; off <<= 1) {
@@ -355,7 +357,7 @@ k_scan1_mid(int bits, u64 *__restrict__ partial, u64 *__restrict__ part_start, u
         u64 run = pre + inc - tot;
         part_start[d] = run;
         if (d == nbins - 1) part_start[nbins] = n_total;
-        for (u32 k = 0; k < SCAN_SLICES; k++) {
+        for (u32 k = 0; k < nsl; k++) {
             const u64 c = partial[(u64)k * nbins + d];
             partial[(u64)k * nbins + d] = run;
             run += c;
@@ -369,7 +371,7 @@ k_scan1_final(const u32 *__restrict__ unit_start, int bits, const u32 *__restric
 {
     const u32 nbins = 1u << bits, nu = unit_start[1];
     u32 ub, ue;
-    slice_range(nu, blockIdx.x, ub, ue);
+    slice_range(nu, gridDim.x, blockIdx.x, ub, ue);
     for (u32 d = threadIdx.x; d < nbins; d += 1024) {
         u64 run = partial[(u64)blockIdx.x * nbins + d];
         for (u32 u = ub; u < ue; u++) {
@@ -1543,9 +1545,11 @@ void launch_scan_units(hipStream_t st, const PassGeom &g, const u64 *d_seg_start
 {
     const size_t nbins = (size_t)1 << g.bits;
     if (g.nseg == 1 && g.max_units > 2 * SCAN_SLICES && d_scan_tmp != nullptr) {
-        hipLaunchKernelGGL(k_scan1_partial, dim3(SCAN_SLICES), dim3(1024), 0, st, d_unit_start, g.bits, d_unit_hist, d_scan_tmp);
-        hipLaunchKernelGGL(k_scan1_mid, dim3(1), dim3(1024), 0, st, g.bits, d_scan_tmp, d_part_start, g.n);
-        hipLaunchKernelGGL(k_scan1_final, dim3(SCAN_SLICES), dim3(1024), 0, st, d_unit_start, g.bits, d_unit_hist,
+        u32 nsl = 8;
+        while (nsl < SCAN_SLICES && nsl * nsl < g.max_units) nsl++;
+        hipLaunchKernelGGL(k_scan1_partial, dim3(nsl), dim3(1024), 0, st, d_unit_start, g.bits, d_unit_hist, d_scan_tmp);
+        hipLaunchKernelGGL(k_scan1_mid, dim3(1), dim3(1024), 0, st, g.bits, nsl, d_scan_tmp, d_part_start, g.n);
+        hipLaunchKernelGGL(k_scan1_final, dim3(nsl), dim3(1024), 0, st, d_unit_start, g.bits, d_unit_hist,
                            d_scan_tmp, d_unit_base);
         return;
     }

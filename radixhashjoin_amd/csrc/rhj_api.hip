@@ -46,6 +46,7 @@ struct rhj_ctx {
     DevBuf part_R, part_S, part_tmp;   // partitioned relations, pass-1 intermediate
     DevBuf ps_R, ps_S, ps_1;           // partition boundaries (final R, final S, pass-1 scratch)
     DevBuf seg0, unit_start, unit_hist, unit_base;
+    DevBuf seg0_b, unit_start_b, unit_hist_b, unit_base_b, scan_tmp_b;   // second relation of a paired pass
     DevBuf tasks, counters;            // counters: [0] u64 out_count, [1] u32 ntasks (+pad), [2] u64 checksum
     DevBuf out_pairs;                  // rhj_join's device result buffer
     DevBuf small_out;                  // small-join path: 64-byte header {count} + pairs, fetched in one D2H
@@ -307,6 +308,39 @@ int run_pass(rhj_ctx *ctx, const void *d_in, void *d_out, u64 n, const u64 *d_se
     return check_launch(ctx, "partition pass");
 }
 
+// One pass over BOTH relations with shared launches (grid.y = relation): 6 launches instead of 12.  Mid-size joins
+// (BASELINE config 2: 1M x 1M, one 8-bit pass) are bound by launch count and by 244-workgroup kernels that fill the
+// chip only halfway.
+int run_pass_pair(rhj_ctx *ctx, const void *d_R, u64 nR, void *outR, u64 *psR, const void *d_S, u64 nS, void *outS, u64 *psS,
+                  int bits)
+{
+    const size_t nbins = (size_t)1 << bits;
+    PassPairHost h;
+    DevBuf *seg[2] = {&ctx->seg0, &ctx->seg0_b}, *ust[2] = {&ctx->unit_start, &ctx->unit_start_b},
+           *uh[2] = {&ctx->unit_hist, &ctx->unit_hist_b}, *ub[2] = {&ctx->unit_base, &ctx->unit_base_b},
+           *sc[2] = {&ctx->scan_tmp, &ctx->scan_tmp_b};
+    const void *in[2] = {d_R, d_S};
+    void *out[2] = {outR, outS};
+    u64 *ps[2] = {psR, psS};
+    const u64 n[2] = {nR, nS};
+    for (int i = 0; i < 2; i++) {
+        const PassGeom g = make_geom(n[i], 1, 0, bits);
+        RHJCHK(ensure(ctx, *seg[i], 64));
+        RHJCHK(ensure(ctx, *ust[i], 16));
+        RHJCHK(ensure(ctx, *uh[i], (size_t)g.max_units * nbins * 4));
+        RHJCHK(ensure(ctx, *ub[i], (size_t)g.max_units * nbins * 8));
+        RHJCHK(ensure(ctx, *sc[i], scan_tmp_bytes(bits)));
+        h.side[i] = PassSide{in[i], out[i], (u64 *)seg[i]->p, (u32 *)ust[i]->p, (u32 *)uh[i]->p, (u64 *)ub[i]->p, ps[i],
+                             (u64 *)sc[i]->p, g};
+    }
+    static const int kinds[4] = {RHJ_K_AUX, RHJ_K_HIST, RHJ_K_SCAN, RHJ_K_SCATTER};
+    for (int phase = 0; phase < 4; phase++) {
+        Span s(ctx, kinds[phase]);
+        launch_pass_pair(ctx->stream, h, 0, bits, phase);
+    }
+    return check_launch(ctx, "paired partition pass");
+}
+
 // Two passes with ONE histogram read (k_hist2d_units): used when both passes fit the write-combining scatter
 // and b1 + b2 <= 16.  Pass-2 units = pieces of each pass-1 bucket written by groups of pass-1 units.
 int partition_relation_fused(rhj_ctx *ctx, const void *d_in, u64 n, int b1, int b2, void *d_out, u64 *d_ps)
@@ -417,8 +451,13 @@ int partition_phase(rhj_ctx *ctx, const void *d_R, u64 nR, const void *d_S, u64 
         RHJCHK(ensure(ctx, ctx->ps_S, (np + 1) * 8));
         RHJCHK(ensure(ctx, ctx->part_R, (size_t)(nR ? nR : 1) * 16));
         RHJCHK(ensure(ctx, ctx->part_S, (size_t)(nS ? nS : 1) * 16));
-        RHJCHK(partition_relation(ctx, d_R, nR, plan.passes, plan.bits1, plan.bits2, ctx->part_R.p, (u64 *)ctx->ps_R.p));
-        RHJCHK(partition_relation(ctx, d_S, nS, plan.passes, plan.bits1, plan.bits2, ctx->part_S.p, (u64 *)ctx->ps_S.p));
+        if (plan.passes == 1 && plan.bits1 <= PASS_PAIR_MAX_BITS) {
+            RHJCHK(run_pass_pair(ctx, d_R, nR, ctx->part_R.p, (u64 *)ctx->ps_R.p, d_S, nS, ctx->part_S.p, (u64 *)ctx->ps_S.p,
+                                 plan.bits1));
+        } else {
+            RHJCHK(partition_relation(ctx, d_R, nR, plan.passes, plan.bits1, plan.bits2, ctx->part_R.p, (u64 *)ctx->ps_R.p));
+            RHJCHK(partition_relation(ctx, d_S, nS, plan.passes, plan.bits1, plan.bits2, ctx->part_S.p, (u64 *)ctx->ps_S.p));
+        }
         ctx->cur_R = ctx->part_R.p;
         ctx->cur_S = ctx->part_S.p;
         ctx->cur_nparts = np;
@@ -558,7 +597,8 @@ int rhj_release_workspace(rhj_ctx *ctx)
     RHJCHK(use_device(ctx));
     (void)hipStreamSynchronize(ctx->stream);
     DevBuf *all[] = {&ctx->in_R, &ctx->in_S, &ctx->part_R, &ctx->part_S, &ctx->part_tmp, &ctx->ps_R, &ctx->ps_S,
-                     &ctx->ps_1, &ctx->seg0, &ctx->unit_start, &ctx->unit_hist, &ctx->unit_base, &ctx->tasks,
+                     &ctx->ps_1, &ctx->seg0, &ctx->unit_start, &ctx->unit_hist, &ctx->unit_base, &ctx->seg0_b,
+                     &ctx->unit_start_b, &ctx->unit_hist_b, &ctx->unit_base_b, &ctx->scan_tmp_b, &ctx->tasks,
                      &ctx->counters, &ctx->out_pairs, &ctx->small_out, &ctx->hist_tmp, &ctx->scan_tmp, &ctx->hist2,
                      &ctx->grp_rng, &ctx->unit_start2};
     for (DevBuf *b : all) release(*b);

@@ -67,6 +67,21 @@ void launch_join_direct(hipStream_t st, const void *d_R, u64 nR, const void *d_S
 void launch_checksum(hipStream_t st, const void *d_pairs, u64 n, u64 *d_sum);
 void launch_generate(hipStream_t st, int kind, void *d_out, u64 n, u64 row0, u64 D, u64 seed, double theta);
 void launch_expected_pkfk(hipStream_t st, const void *d_S, u64 n, u64 *d_sum);
+// one partition pass over both relations of a join with shared launches (one-pass plans)
+struct PassSide {
+    const void *in;
+    void *out;
+    u64 *seg_start;
+    u32 *unit_start;
+    u32 *unit_hist;
+    u64 *unit_base;
+    u64 *part_start;
+    u64 *scan_tmp;
+    PassGeom g;
+};
+struct PassPairHost { PassSide side[2]; };
+void launch_pass_pair(hipStream_t st, const PassPairHost &h, int shift, int bits, int phase);
+constexpr int PASS_PAIR_MAX_BITS = 9;            // the write-combining scatter's range
 bool fused_two_pass_ok(int b1, int b2);
 // bucket-join kernels: JK_BKT partitions that fit one 4224-tuple table (two workgroups per CU); JK_BKT_BIG 8448-tuple
 // chunks, probe side re-read per chunk (any radix plan); JK_CT compact 8-byte entries, both sides read once

@@ -97,6 +97,31 @@ __global__ void k_init_single_segment(u64 n, u64 L, u64 *seg_start, u32 *unit_st
     }
 }
 
+// ---- both relations of a join through the same launches (one-pass plans: mid-size joins are launch-bound) -----------
+// blockIdx.y selects the relation; the kernels below are the single-relation bodies called with that relation's arguments.
+struct PassRel {                      // one relation's side of a partition pass
+    const Tup *in;
+    Tup *out;
+    u64 *seg_start;                   // {0, n}
+    u32 *unit_start;                  // {0, units}
+    u32 *unit_hist;
+    u64 *unit_base;
+    u64 *part_start;
+    u64 *scan_tmp;
+    u64 n, L;
+    u32 max_units;
+};
+struct PassPair { PassRel r[2]; };
+
+__global__ void k_init_single_segment2(PassPair a)
+{
+    const PassRel &x = a.r[blockIdx.x];
+    if (threadIdx.x == 0) {
+        x.seg_start[0] = 0; x.seg_start[1] = x.n;
+        x.unit_start[0] = 0; x.unit_start[1] = (u32)((x.n + x.L - 1) / x.L);
+    }
+}
+
 // unit_start[s] = sum_{s'<s} ceil(size(s') / L), one workgroup, nseg arbitrary
 __global__ void __launch_bounds__(1024) k_make_units(const u64 *__restrict__ seg_start, u32 nseg, u64 L,
                                                      u32 *__restrict__ unit_start)
@@ -125,14 +150,13 @@ __global__ void __launch_bounds__(1024) k_make_units(const u64 *__restrict__ seg
 // over a row range.  16 B/lane coalesced loads (the rowID rides along in the same 128 B line),
 // LDS histogram per workgroup, one flush per unit.
 // ------------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(PART_THREADS)
-k_hist_units(const Tup *__restrict__ in, const u64 *__restrict__ seg_start, const u32 *__restrict__ unit_start,
-             u32 nseg, u64 L, int shift, int bits, u32 *__restrict__ unit_hist)
+__device__ __forceinline__ void
+dev_hist_units(const Tup *__restrict__ in, const u64 *__restrict__ seg_start, const u32 *__restrict__ unit_start,
+               u32 nseg, u64 L, int shift, int bits, u32 *__restrict__ unit_hist, const u32 u)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     u32 *cnt = reinterpret_cast<u32 *>(smem);
     const u32 nbins = 1u << bits, mask = nbins - 1;
-    const u32 u = blockIdx.x;
     if (u >= unit_start[nseg]) return;
     const u32 s = find_segment(unit_start, nseg, u);
     const u64 beg = seg_start[s] + (u64)(u - unit_start[s]) * L;
@@ -155,6 +179,20 @@ k_hist_units(const Tup *__restrict__ in, const u64 *__restrict__ seg_start, cons
     __syncthreads();
     u32 *out = unit_hist + (u64)u * nbins;
     for (u32 b = threadIdx.x; b < nbins; b += PART_THREADS) out[b] = cnt[b];
+}
+
+__global__ void __launch_bounds__(PART_THREADS)
+k_hist_units(const Tup *__restrict__ in, const u64 *__restrict__ seg_start, const u32 *__restrict__ unit_start,
+             u32 nseg, u64 L, int shift, int bits, u32 *__restrict__ unit_hist)
+{
+    dev_hist_units(in, seg_start, unit_start, nseg, L, shift, bits, unit_hist, blockIdx.x);
+}
+
+__global__ void __launch_bounds__(PART_THREADS) k_hist_units2(PassPair a, int shift, int bits)
+{
+    const PassRel &x = a.r[blockIdx.y];
+    if (blockIdx.x >= x.max_units) return;
+    dev_hist_units(x.in, x.seg_start, x.unit_start, 1u, x.L, shift, bits, x.unit_hist, blockIdx.x);
 }
 
 
@@ -249,9 +287,10 @@ __global__ void k_make_group_ranges(const u64 *__restrict__ unit_base1, u32 nb1,
 //       cursor: what PartitionJob's local prefix + the bucket-major/range-minor merge amount to)
 // One workgroup (1024 threads = G groups x nbins digits) per segment; nbins <= 1024.
 // ------------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(1024)
-k_scan_units(const u64 *__restrict__ seg_start, const u32 *__restrict__ unit_start, u32 nseg, int bits,
-             const u32 *__restrict__ unit_hist, u64 *__restrict__ unit_base, u64 *__restrict__ part_start, u64 n_total)
+__device__ __forceinline__ void
+dev_scan_units(const u64 *__restrict__ seg_start, const u32 *__restrict__ unit_start, u32 nseg, int bits,
+               const u32 *__restrict__ unit_hist, u64 *__restrict__ unit_base, u64 *__restrict__ part_start, u64 n_total,
+               const u32 s)
 {
     // 64-bit sums throughout: a segment (a whole relation, or one pass-1 bucket of a skewed multi-billion-tuple
     // input) may hold 2^32 tuples or more; only a UNIT's counts (<= L tuples) are 32-bit
@@ -260,7 +299,6 @@ k_scan_units(const u64 *__restrict__ seg_start, const u32 *__restrict__ unit_sta
     __shared__ u64 wtot[16];
     const u32 nbins = 1u << bits;
     const u32 G = 1024u / nbins;                        // >= 1
-    const u32 s = blockIdx.x;
     const u32 d = threadIdx.x & (nbins - 1), g = threadIdx.x >> bits;
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const u32 us = unit_start[s], ue = unit_start[s + 1];
@@ -305,6 +343,19 @@ k_scan_units(const u64 *__restrict__ seg_start, const u32 *__restrict__ unit_sta
     }
 }
 
+__global__ void __launch_bounds__(1024)
+k_scan_units(const u64 *__restrict__ seg_start, const u32 *__restrict__ unit_start, u32 nseg, int bits,
+             const u32 *__restrict__ unit_hist, u64 *__restrict__ unit_base, u64 *__restrict__ part_start, u64 n_total)
+{
+    dev_scan_units(seg_start, unit_start, nseg, bits, unit_hist, unit_base, part_start, n_total, blockIdx.x);
+}
+
+__global__ void __launch_bounds__(1024) k_scan_units2(PassPair a, int bits)
+{
+    const PassRel &x = a.r[blockIdx.x];
+    dev_scan_units(x.seg_start, x.unit_start, 1u, bits, x.unit_hist, x.unit_base, x.part_start, x.n, 0u);
+}
+
 
 // K2 for ONE long segment (pass 1: up to ~2048 units): the same result as k_scan_units, computed by
 // up to SCAN_SLICES workgroups in three short launches instead of one workgroup walking every unit.  The number of
@@ -320,8 +371,8 @@ __device__ __forceinline__ void slice_range(u32 nu, u32 nsl, u32 k, u32 &ub, u32
 }
 
 // partial[k][d] = sum of hist[u][d] over the units of slice k
-__global__ void __launch_bounds__(1024)
-k_scan1_partial(const u32 *__restrict__ unit_start, int bits, const u32 *__restrict__ unit_hist, u64 *__restrict__ partial)
+__device__ __forceinline__ void
+dev_scan1_partial(const u32 *__restrict__ unit_start, int bits, const u32 *__restrict__ unit_hist, u64 *__restrict__ partial)
 {
     const u32 nbins = 1u << bits, nu = unit_start[1];
     u32 ub, ue;
@@ -333,9 +384,21 @@ k_scan1_partial(const u32 *__restrict__ unit_start, int bits, const u32 *__restr
     }
 }
 
-// partial[k][d] <- part_start[d] + sum_{k'<k} partial[k'][d];  part_start[d] = exclusive prefix of the digit totals
 __global__ void __launch_bounds__(1024)
-k_scan1_mid(int bits, u32 nsl, u64 *__restrict__ partial, u64 *__restrict__ part_start, u64 n_total)
+k_scan1_partial(const u32 *__restrict__ unit_start, int bits, const u32 *__restrict__ unit_hist, u64 *__restrict__ partial)
+{
+    dev_scan1_partial(unit_start, bits, unit_hist, partial);
+}
+
+__global__ void __launch_bounds__(1024) k_scan1_partial2(PassPair a, int bits)
+{
+    const PassRel &x = a.r[blockIdx.y];
+    dev_scan1_partial(x.unit_start, bits, x.unit_hist, x.scan_tmp);
+}
+
+// partial[k][d] <- part_start[d] + sum_{k'<k} partial[k'][d];  part_start[d] = exclusive prefix of the digit totals
+__device__ __forceinline__ void
+dev_scan1_mid(int bits, u32 nsl, u64 *__restrict__ partial, u64 *__restrict__ part_start, u64 n_total)
 {
     __shared__ u64 wtot[16];
     const u32 nbins = 1u << bits;                         // <= 1024
@@ -366,8 +429,20 @@ k_scan1_mid(int bits, u32 nsl, u64 *__restrict__ partial, u64 *__restrict__ part
 }
 
 __global__ void __launch_bounds__(1024)
-k_scan1_final(const u32 *__restrict__ unit_start, int bits, const u32 *__restrict__ unit_hist,
-              const u64 *__restrict__ partial, u64 *__restrict__ unit_base)
+k_scan1_mid(int bits, u32 nsl, u64 *__restrict__ partial, u64 *__restrict__ part_start, u64 n_total)
+{
+    dev_scan1_mid(bits, nsl, partial, part_start, n_total);
+}
+
+__global__ void __launch_bounds__(1024) k_scan1_mid2(PassPair a, int bits, u32 nsl)
+{
+    const PassRel &x = a.r[blockIdx.x];
+    dev_scan1_mid(bits, nsl, x.scan_tmp, x.part_start, x.n);
+}
+
+__device__ __forceinline__ void
+dev_scan1_final(const u32 *__restrict__ unit_start, int bits, const u32 *__restrict__ unit_hist,
+                const u64 *__restrict__ partial, u64 *__restrict__ unit_base)
 {
     const u32 nbins = 1u << bits, nu = unit_start[1];
     u32 ub, ue;
@@ -379,6 +454,19 @@ k_scan1_final(const u32 *__restrict__ unit_start, int bits, const u32 *__restric
             run += unit_hist[(u64)u * nbins + d];
         }
     }
+}
+
+__global__ void __launch_bounds__(1024)
+k_scan1_final(const u32 *__restrict__ unit_start, int bits, const u32 *__restrict__ unit_hist,
+              const u64 *__restrict__ partial, u64 *__restrict__ unit_base)
+{
+    dev_scan1_final(unit_start, bits, unit_hist, partial, unit_base);
+}
+
+__global__ void __launch_bounds__(1024) k_scan1_final2(PassPair a, int bits)
+{
+    const PassRel &x = a.r[blockIdx.y];
+    dev_scan1_final(x.unit_start, bits, x.unit_hist, x.scan_tmp, x.unit_base);
 }
 
 
@@ -519,10 +607,10 @@ constexpr int WC_THREADS_SMALL = 512;                                       // <
 constexpr int WC_MAX_BITS = 9;
 
 template <int THREADS>
-__global__ void __launch_bounds__(THREADS)
-k_scatter_wc(const Tup *__restrict__ in, Tup *__restrict__ out, const u64 *__restrict__ seg_start,
-             const u32 *__restrict__ unit_start, u32 nseg, u64 L, int shift, int bits,
-             const u64 *__restrict__ unit_base, const u64 *__restrict__ unit_rng, u32 n_rng_units)
+__device__ __forceinline__ void
+dev_scatter_wc(const Tup *__restrict__ in, Tup *__restrict__ out, const u64 *__restrict__ seg_start,
+               const u32 *__restrict__ unit_start, u32 nseg, u64 L, int shift, int bits,
+               const u64 *__restrict__ unit_base, const u64 *__restrict__ unit_rng, u32 n_rng_units, const u32 u)
 {
     constexpr int TILE = THREADS * WC_TPT;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -538,7 +626,6 @@ k_scatter_wc(const Tup *__restrict__ in, Tup *__restrict__ out, const u64 *__res
     u32 *mtot = LO + nbins;                                                  // staged tuples of this tile
     u32 *wsc = mtot + 4;                                                     // THREADS/64 wave totals
 
-    const u32 u = blockIdx.x;
     u64 beg, end;
     if (unit_rng != nullptr) {               // explicit unit ranges (fused two-pass plan: units of pass 2 are
         if (u >= n_rng_units) return;        // the pieces of a bucket written by groups of pass-1 units)
@@ -671,6 +758,24 @@ k_scatter_wc(const Tup *__restrict__ in, Tup *__restrict__ out, const u64 *__res
         const u64 g = gnext[d];
         if (j >= LO[d] && j < ((u32)g & 7u)) out[(g & ~7ull) + j] = cb[q];
     }
+}
+
+template <int THREADS>
+__global__ void __launch_bounds__(THREADS)
+k_scatter_wc(const Tup *__restrict__ in, Tup *__restrict__ out, const u64 *__restrict__ seg_start,
+             const u32 *__restrict__ unit_start, u32 nseg, u64 L, int shift, int bits,
+             const u64 *__restrict__ unit_base, const u64 *__restrict__ unit_rng, u32 n_rng_units)
+{
+    dev_scatter_wc<THREADS>(in, out, seg_start, unit_start, nseg, L, shift, bits, unit_base, unit_rng, n_rng_units, blockIdx.x);
+}
+
+template <int THREADS>
+__global__ void __launch_bounds__(THREADS) k_scatter_wc2(PassPair a, int shift, int bits)
+{
+    const PassRel &x = a.r[blockIdx.y];
+    if (blockIdx.x >= x.max_units) return;
+    dev_scatter_wc<THREADS>(x.in, x.out, x.seg_start, x.unit_start, 1u, x.L, shift, bits, x.unit_base, (const u64 *)nullptr, 0u,
+                            blockIdx.x);
 }
 
 // d_hist[b] = d_start[b+1] - d_start[b]
@@ -1506,6 +1611,10 @@ static void allow_big_lds()
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)wc_lds_bytes(WC_MAX_BITS, WC_THREADS));
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_scatter_wc<WC_THREADS_SMALL>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)wc_lds_bytes(WC_MAX_BITS, WC_THREADS_SMALL));
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_scatter_wc2<WC_THREADS>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)wc_lds_bytes(WC_MAX_BITS, WC_THREADS));
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_scatter_wc2<WC_THREADS_SMALL>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)wc_lds_bytes(WC_MAX_BITS, WC_THREADS_SMALL));
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_join_bkt<BJ_THREADS, BJ_CHUNK, BJ_BUCKET_BITS, BJ_EPT, false>),
                               hipFuncAttributeMaxDynamicSharedMemorySize,
                               (int)bj_lds_bytes(BJ_THREADS, BJ_CHUNK, BJ_BUCKET_BITS));
@@ -1578,6 +1687,43 @@ void launch_scatter_units(hipStream_t st, const void *d_in, void *d_out, const P
     hipLaunchKernelGGL(k_scatter_units_pipe, dim3(g.max_units), dim3(PART_THREADS), part_lds_bytes(g.bits), st,
                        (const Tup *)d_in, (Tup *)d_out, d_seg_start, d_unit_start, g.nseg, g.L, g.shift, g.bits,
                        d_unit_base);
+}
+
+// One partition pass over BOTH relations of a join, each kernel launched once (grid.y = relation).  bits <= WC_MAX_BITS.
+// phase: 0 unit tables, 1 histogram, 2 scan, 3 scatter (separate calls so that the host can time them per kind).
+void launch_pass_pair(hipStream_t st, const PassPairHost &h, int shift, int bits, int phase)
+{
+    allow_big_lds();
+    PassPair a;
+    u32 mu = 0;
+    for (int i = 0; i < 2; i++) {
+        const PassSide &x = h.side[i];
+        a.r[i] = PassRel{(const Tup *)x.in, (Tup *)x.out, x.seg_start, x.unit_start, x.unit_hist, x.unit_base, x.part_start,
+                         x.scan_tmp, x.g.n, x.g.L, x.g.max_units};
+        mu = x.g.max_units > mu ? x.g.max_units : mu;
+    }
+    if (mu == 0) return;
+    if (phase == 0) {
+        hipLaunchKernelGGL(k_init_single_segment2, dim3(2), dim3(64), 0, st, a);
+    } else if (phase == 1) {
+        hipLaunchKernelGGL(k_hist_units2, dim3(mu, 2), dim3(PART_THREADS), ((size_t)4 << bits), st, a, shift, bits);
+    } else if (phase == 2) {
+        if (mu > 2 * SCAN_SLICES) {
+            u32 nsl = 8;
+            while (nsl < SCAN_SLICES && nsl * nsl < mu) nsl++;
+            hipLaunchKernelGGL(k_scan1_partial2, dim3(nsl, 2), dim3(1024), 0, st, a, bits);
+            hipLaunchKernelGGL(k_scan1_mid2, dim3(2), dim3(1024), 0, st, a, bits, nsl);
+            hipLaunchKernelGGL(k_scan1_final2, dim3(nsl, 2), dim3(1024), 0, st, a, bits);
+        } else {
+            const size_t nbins = (size_t)1 << bits, G = 1024 / nbins;
+            hipLaunchKernelGGL(k_scan_units2, dim3(2), dim3(1024), G * nbins * 8, st, a, bits);
+        }
+    } else if (wc_threads_for(bits) == WC_THREADS_SMALL) {
+        hipLaunchKernelGGL(k_scatter_wc2<WC_THREADS_SMALL>, dim3(mu, 2), dim3(WC_THREADS_SMALL), wc_lds_bytes(bits, WC_THREADS_SMALL),
+                           st, a, shift, bits);
+    } else {
+        hipLaunchKernelGGL(k_scatter_wc2<WC_THREADS>, dim3(mu, 2), dim3(WC_THREADS), wc_lds_bytes(bits, WC_THREADS), st, a, shift, bits);
+    }
 }
 
 bool fused_two_pass_ok(int b1, int b2) { return b1 >= 1 && b2 >= 1 && b1 <= WC_MAX_BITS && b2 <= WC_MAX_BITS && b1 + b2 <= 16; }

@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """tests/fuzz_gpu.py -- randomized differential test of the HIP path against the CPU oracle (run by hand on the GPU box).
 Random sizes (incl. tile/unit/table boundaries), value domains, duplicate structure, skew, radix plans and
-probe splits; compares (count, checksum) and, for small outputs, the sorted pair sets.  python tests/fuzz_gpu.py [seconds] [seed]"""
+probe splits; compares (count, checksum) and, for small outputs, the sorted pair sets.  python tests/fuzz_gpu.py [seconds] [seed]
+RHJ_FUZZ_BIG=1|2 forces the oversized-partition kernels (1: chunked 16-byte entries, 2: compact table where the plan allows)."""
 import os, sys, time
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -12,6 +13,9 @@ budget = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
 seed = int(sys.argv[2]) if len(sys.argv) > 2 else 12345
 rng = np.random.default_rng(seed)
 o, e = Oracle(), rhj.Engine(0)
+if os.environ.get("RHJ_FUZZ_BIG"):
+    e.set_option("join.big_tables", 1)
+    e.set_option("join.big_kernel", int(os.environ["RHJ_FUZZ_BIG"]))
 EDGE = [1, 2, 7, 8, 9, 63, 64, 65, 2047, 2048, 2049, 4095, 4096, 4097, 4223, 4224, 4225, 8447, 8448, 8449, 32767, 32768, 32769]
 
 
@@ -65,8 +69,10 @@ while time.time() - t0 < budget:
         opts = rhj.Opts(0, 0, 0, int(rng.choice([0, 4096, 8192])))
     elif r < 0.75:
         opts = rhj.Opts(1, int(rng.integers(1, 11)), 0, int(rng.choice([0, 4096])))
-    else:
+    elif r < 0.9 or not os.environ.get("RHJ_FUZZ_BIG"):
         opts = rhj.Opts(2, int(rng.integers(1, 11)), int(rng.integers(1, 11)), int(rng.choice([0, 4096, 32768])))
+    else:                                                                    # >= 16 bits: what the compact-table kernel serves
+        opts = rhj.Opts(2, int(rng.integers(8, 11)), int(rng.integers(8, 11)), int(rng.choice([0, 4096, 32768])))
     got = e.join(R, S, opts=opts)
     ok = (len(got), o.pairs_checksum(got)) == (exp_n, exp_c)
     if ok and exp_n <= 300_000:

@@ -263,7 +263,8 @@ PassGeom make_geom(u64 n, u32 nseg, int shift, int bits)
 {
     PassGeom g;
     g.n = n;
-    u64 L = (n + PART_TARGET_UNITS - 1) / PART_TARGET_UNITS;
+    static const u64 target_units = getenv("RHJ_UNITS") ? strtoull(getenv("RHJ_UNITS"), nullptr, 10) : PART_TARGET_UNITS;   // tuning aid
+    u64 L = (n + target_units - 1) / target_units;
     L = (L + PART_TILE - 1) / PART_TILE * PART_TILE;
     if (L < (u64)PART_TILE) L = PART_TILE;
     g.L = L;

@@ -10,6 +10,10 @@
 // k_make_tasks           JoinJob scheduling loop      Result.cpp:98-107            latency
 // k_join_bkt             JoinJob::run, join_buckets,  JobScheduler.cpp:186-192,
 //                        add_result / addAll          Result.cpp:43-76, 21-35      HBM read+write (16 B/tuple + 16 B/pair)
+//                        (partitions that fit one 16 B/entry LDS table; DIRECT: small unpartitioned joins, no task list)
+// k_join_ct              the same for partitions of up to 17920 build tuples under plans that remove >= 16 payload
+//                        bits: 8 B entries, both sides read once                           HBM + LDS latency
+// k_*2                   the one-pass kernels with grid.y = relation: R and S of a join through the same launches
 //
 // No MFMA anywhere: the path is 64-bit integer hashing and data movement, bounded by HBM.
 #include "rhj_internal.h"

@@ -10,6 +10,7 @@ from radixhashjoin_amd import Opts, RhjError
 from radixhashjoin_amd.binding import GEN_CONST, GEN_R, GEN_S_DISJOINT, GEN_S_UNIFORM, GEN_S_ZIPF, RHJ_E_OVERFLOW
 
 pytestmark = pytest.mark.gpu
+ROOT_DIR = __import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__)))
 
 GOLDEN_CASES = ["pkfk_1k", "pkfk_1m", "pkfk_16m", "pkfk_4m_x_1m", "pkfk_300k_x_3m", "dup_10k", "dup_100k_50k",
                 "dup_2m_d64k", "alleq_300_500", "alleq_7000_9", "tinyR_1_1000", "tinyS_1000_1", "tiny_5_3",
@@ -393,3 +394,37 @@ def test_dev_alloc_recycles_blocks(engine):
     assert free1 >= free0
     c = engine.alloc(3_000_000)                 # still usable after the flush
     c.free()
+
+
+def test_first_ever_join_from_8_threads_at_once():
+    """A FRESH process whose first eight joins start at the same time from eight threads (MainScheduler's query threads,
+    MainScheduler.cpp:6-14): the per-device kernel attributes (large dynamic LDS) must be in place before any of them
+    launches -- they are applied under std::call_once.  Partitioned joins, so that k_scatter_wc and k_join_bkt need them."""
+    import subprocess
+    import sys
+    import textwrap
+    code = textwrap.dedent("""
+        import sys, threading
+        sys.path.insert(0, %r)
+        import numpy as np
+        import radixhashjoin_amd as rhj
+        from oracle.pyoracle import Oracle
+        o = Oracle()
+        R, S = o.gen_R(300_000), o.gen_S_counter(500_000, 300_000, 5)
+        exp = o.join_count_checksum(R, S)
+        engines = [rhj.Engine(0) for _ in range(8)]          # contexts only: no kernel has been launched yet
+        start, errors = threading.Barrier(8), []
+        def work(e):
+            try:
+                start.wait()
+                p = e.join(R, S)
+                assert (len(p), o.pairs_checksum(p)) == exp
+            except Exception as ex:
+                errors.append(repr(ex))
+        ts = [threading.Thread(target=work, args=(e,)) for e in engines]
+        [t.start() for t in ts]; [t.join() for t in ts]
+        assert not errors, errors
+        print("ok")
+    """) % ROOT_DIR
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0 and out.stdout.strip().endswith("ok"), out.stderr[-2000:]

@@ -259,11 +259,12 @@ int resolve_plan(u64 nR, u64 nS, const rhj_opts *in, rhj_opts *out)
     return RHJ_OK;
 }
 
-PassGeom make_geom(u64 n, u32 nseg, int shift, int bits)
+PassGeom make_geom(u64 n, u32 nseg, int shift, int bits, u64 target_units = PART_TARGET_UNITS)
 {
     PassGeom g;
     g.n = n;
-    static const u64 target_units = getenv("RHJ_UNITS") ? strtoull(getenv("RHJ_UNITS"), nullptr, 10) : PART_TARGET_UNITS;   // tuning aid
+    static const u64 forced_units = getenv("RHJ_UNITS") ? strtoull(getenv("RHJ_UNITS"), nullptr, 10) : 0;   // tuning aid
+    if (forced_units) target_units = forced_units;
     u64 L = (n + target_units - 1) / target_units;
     L = (L + PART_TILE - 1) / PART_TILE * PART_TILE;
     if (L < (u64)PART_TILE) L = PART_TILE;
@@ -346,9 +347,11 @@ int run_pass_pair(rhj_ctx *ctx, const void *d_R, u64 nR, void *outR, u64 *psR, c
 // and b1 + b2 <= 16.  Pass-2 units = pieces of each pass-1 bucket written by groups of pass-1 units.
 int partition_relation_fused(rhj_ctx *ctx, const void *d_in, u64 n, int b1, int b2, void *d_out, u64 *d_ps)
 {
-    const PassGeom g1 = make_geom(n, 1, 0, b1);
+    // 1024 pass-1 units instead of 2048: every unit flushes a 2^(b1+b2)-bin table, and the scatter does not care
+    // ([measured] at 10^9 tuples: histogram 2.54 against 2.74 ms, scatter within noise)
+    const PassGeom g1 = make_geom(n, 1, 0, b1, PART_TARGET_UNITS / 2);
     const u32 units1 = (u32)((n + g1.L - 1) / g1.L);
-    const u32 want_groups = 16;
+    static const u32 want_groups = getenv("RHJ_GROUPS") ? (u32)atoi(getenv("RHJ_GROUPS")) : 16u;   // tuning aid
     const u32 per = units1 ? (units1 + want_groups - 1) / want_groups : 1;
     const u32 ngroups = units1 ? (units1 + per - 1) / per : 1;
     const size_t nb1 = (size_t)1 << b1, nb2 = (size_t)1 << b2;

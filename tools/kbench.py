@@ -22,6 +22,8 @@ ap.add_argument("--label", default="")
 ap.add_argument("--probe-split", type=int, default=0)
 ap.add_argument("--no-join", action="store_true", help="partition stage only (safe for ablations that corrupt outputs)")
 ap.add_argument("--join-only", action="store_true", help="partition once, then time rhj_bucket_join alone")
+ap.add_argument("--auto", action="store_true", help="the engine's automatic radix plan instead of --passes/--bits")
+ap.add_argument("--big", type=int, default=-1, help="rhj_set_option join.big_kernel (1: chunked 16 B entries, 2: compact table)")
 a = ap.parse_args()
 
 e = rhj.Engine(0)
@@ -30,7 +32,9 @@ dR, dS, dO = e.alloc(16 * n), e.alloc(16 * n), e.alloc(16 * n)
 e.generate(GEN_R, dR, n, 0, n)
 e.generate(GEN_S_ZIPF if a.dist == "zipf" else GEN_S_UNIFORM, dS, n, 0, n, seed=42, theta_milli=900)
 exp = e.expected_pkfk(dS, n)
-opts = rhj.Opts(a.passes, a.bits1, a.bits2 if a.passes == 2 else 0, a.probe_split)
+opts = None if a.auto else rhj.Opts(a.passes, a.bits1, a.bits2 if a.passes == 2 else 0, a.probe_split)
+if a.big >= 0:
+    e.set_option("join.big_kernel", a.big)
 if a.no_join:
     dP = e.alloc(8 * ((1 << (a.bits1 + (a.bits2 if a.passes == 2 else 0))) + 1))
     e.partition(dR, n, a.bits1, a.bits2 if a.passes == 2 else 0, dO, dP)
@@ -75,7 +79,8 @@ for _ in range(a.reps):
     ntasks = t["ntasks"]
 ok = (cnt, e.pairs_checksum(dO, cnt)) == exp
 per = {k: v[0] / max(v[1], 1) for k, v in acc.items()}
-res = {"label": a.label or os.environ.get("RHJ_VARIANT", ""), "n": n, "bits": [a.bits1, a.bits2], "ok": ok,
+pl = e.timings()
+res = {"label": a.label or os.environ.get("RHJ_VARIANT", ""), "n": n, "bits": [pl["bits1"], pl["bits2"]] if a.auto else [a.bits1, a.bits2], "ok": ok,
        "hist_ms": round(per["hist"], 3), "hist_GBs(16B/t)": round(16 * n / per["hist"] / 1e6, 0) if per["hist"] else 0,
        "scatter_ms": round(per["scatter"], 3), "scatter_GBs(32B/t)": round(32 * n / per["scatter"] / 1e6, 0) if per["scatter"] else 0,
        "scan_ms": round(per["scan"], 3),

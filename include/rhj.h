@@ -88,7 +88,8 @@ int  rhj_set_stream(rhj_ctx *ctx, void *hip_stream);
 int  rhj_set_profiling(rhj_ctx *ctx, int enabled);
 /* tuning / test knobs; results never depend on them.  "join.big_tables": -1 (default) choose the bucket-join kernel by
  * the average build partition, 0 always the one-table kernel, 1 always an oversized-partition kernel;
- * "join.big_kernel": -1 automatic, 1 the chunked 16-byte-entry kernel, 2 the compact-table kernel where the plan allows. */
+ * "join.big_kernel": -1 automatic, 1 the chunked 16-byte-entry kernel, 2 / 3 the compact-table kernel at full / half size
+ * where the plan allows. */
 int  rhj_set_option(rhj_ctx *ctx, const char *name, int64_t value);
 int  rhj_get_timings(rhj_ctx *ctx, rhj_timings *out);
 int  rhj_sync(rhj_ctx *ctx);                             /* JobScheduler::barrier (JobScheduler.cpp:103-122) */

@@ -484,8 +484,17 @@ int join_phase_on(rhj_ctx *ctx, const void *d_Rp, const u64 *d_psR, u64 nR, cons
     // chunks.  The compact-table kernel keeps a task's probe rowIDs in registers, so a task is at most that many tuples.
     const u64 nbuild = nR < nS ? nR : nS;
     int kind = JK_BKT;
-    if (ctx->opt_big_tables == 1 || (ctx->opt_big_tables < 0 && nbuild / nparts > (u64)BJ_CHUNK))
-        kind = (radix_bits >= join_ct_min_radix_bits() && ctx->opt_big_kernel != JK_BKT_BIG) ? JK_CT : JK_BKT_BIG;
+    if (ctx->opt_big_tables == 1 || (ctx->opt_big_tables < 0 && nbuild / nparts > (u64)BJ_CHUNK)) {
+        if (radix_bits < join_ct_min_radix_bits() || ctx->opt_big_kernel == JK_BKT_BIG) kind = JK_BKT_BIG;
+        else if (ctx->opt_big_kernel == JK_CT || ctx->opt_big_kernel == JK_CT_HALF) kind = ctx->opt_big_kernel;
+        else {  // the compact-table kernel at half size (two workgroups per CU) while the average partition fits its table
+                // AND its 8192-tuple probe tasks (a partition cut into two tasks builds its table twice)
+            const u64 nprobe = nR < nS ? nS : nR;
+            const bool half = nbuild / nparts <= (u64)join_table_tuples(JK_CT_HALF) * 15 / 16 &&
+                              nprobe / nparts <= (u64)join_probe_split(JK_CT_HALF) * 15 / 16;
+            kind = half ? JK_CT_HALF : JK_CT;
+        }
+    }
     if (join_probe_split(kind) && probe_split > join_probe_split(kind)) probe_split = join_probe_split(kind);
     const u64 max_tasks64 = nparts + (nR + nS) / probe_split + 1;
     if (max_tasks64 > 0x7fffffffull) return fail(ctx, RHJ_E_INVALID, "too many join tasks");
@@ -645,7 +654,10 @@ int rhj_set_option(rhj_ctx *ctx, const char *name, int64_t value)
     if (!ctx || !name) return fail(ctx, RHJ_E_INVALID, "rhj_set_option: null argument");
     const std::string n(name);
     if (n == "join.big_tables" && value >= -1 && value <= 1) { ctx->opt_big_tables = (int)value; return RHJ_OK; }
-    if (n == "join.big_kernel" && (value == -1 || value == JK_BKT_BIG || value == JK_CT)) { ctx->opt_big_kernel = (int)value; return RHJ_OK; }
+    if (n == "join.big_kernel" && (value == -1 || value == JK_BKT_BIG || value == JK_CT || value == JK_CT_HALF)) {
+        ctx->opt_big_kernel = (int)value;
+        return RHJ_OK;
+    }
     return fail(ctx, RHJ_E_INVALID, "rhj_set_option: unknown option or value: " + n);
 }
 

@@ -2,7 +2,8 @@
 """tests/fuzz_gpu.py -- randomized differential test of the HIP path against the CPU oracle (run by hand on the GPU box).
 Random sizes (incl. tile/unit/table boundaries), value domains, duplicate structure, skew, radix plans and
 probe splits; compares (count, checksum) and, for small outputs, the sorted pair sets.  python tests/fuzz_gpu.py [seconds] [seed]
-RHJ_FUZZ_BIG=1|2 forces the oversized-partition kernels (1: chunked 16-byte entries, 2: compact table where the plan allows)."""
+RHJ_FUZZ_BIG=1|2|3 forces the oversized-partition kernels (1: chunked 16-byte entries, 2 / 3: compact table at full / half
+size where the plan allows)."""
 import os, sys, time
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))

@@ -15,10 +15,10 @@ from radixhashjoin_amd import Engine, Opts
 from radixhashjoin_amd.binding import GEN_CONST, GEN_R, GEN_S_UNIFORM, GEN_S_ZIPF
 
 pytestmark = pytest.mark.gpu
-BKT_BIG, CT = 1, 2
+BKT_BIG, CT, CT_HALF = 1, 2, 3
 
 
-@pytest.fixture(scope="module", params=[BKT_BIG, CT], ids=["bkt_big", "compact_table"])
+@pytest.fixture(scope="module", params=[BKT_BIG, CT, CT_HALF], ids=["bkt_big", "compact_table", "compact_table_half"])
 def big(request):
     e = Engine(0)
     e.set_option("join.big_tables", 1)
@@ -50,6 +50,7 @@ def check(engine, oracle, R, S, plan):
 
 
 @pytest.mark.parametrize("nR,nS,nlow", [(60_000, 200_000, 3),        # 20 K build / 66 K probe per partition: 2 chunks, 5 tasks
+                                        (8_960, 8_192, 1), (8_961, 8_193, 1),   # the half-size table / task, and one beyond
                                         (200_000, 50_000, 4),        # build on S (the smaller bucket), pairs stay (rowR,rowS)
                                         (17_920, 16_384, 1),         # exactly one table, exactly one task
                                         (17_921, 16_385, 1),         # one tuple beyond each

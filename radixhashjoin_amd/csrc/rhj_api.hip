@@ -236,9 +236,10 @@ int resolve_plan(u64 nR, u64 nS, const rhj_opts *in, rhj_opts *out)
                 // 18-bit plan re-reads each relation once more just to count (10.7 instead of 5.4 ms per 10^9-tuple join).
                 // Partitions that 16 bits leave larger than one 16-byte-entry table go to the compact-table bucket join
                 // (one 17920-entry table, both sides read once), which costs less than that extra read: measured at
-                // 10^9 x 10^9, 8+8 bits 43 ms against 49 ms for 9+9.  Beyond ~2.3 * 10^9 tuples per side its tables
-                // need chunks and 9+9 bits (the widest line-aligned write-combining scatter) takes over.
-                if (bits > 16) bits = nb <= 2 * (u64)65536 * 16800 ? 16 : 18;
+                // 10^9 x 10^9, 8+8 bits 43 ms against 49 ms for 9+9.  Beyond 1.1 * 10^9 tuples per side a 16-bit partition
+                // no longer fits ONE compact table (chunks: probe payloads streamed again per chunk) and 9+9 bits (the
+                // widest line-aligned write-combining scatter) takes over: 2.2 * 10^9 x 2.2 * 10^9, 121.6 against 125.3 ms.
+                if (bits > 16) bits = nb <= (u64)65536 * 16800 ? 16 : 18;
                 o.passes = 2; o.bits1 = (bits + 1) / 2; o.bits2 = bits / 2;
             }
         }

@@ -51,6 +51,8 @@ def test_plan_auto():
                                                         # histogram read) + the compact-table bucket join instead
     p = P(10**9, 10**9, O(2, 8, 8))
     assert (p.passes, p.bits1, p.bits2) == (2, 8, 8)    # BASELINE config 3 as named
+    p = P(2 * 10**9, 2 * 10**9)
+    assert (p.passes, p.bits1, p.bits2) == (2, 9, 9)    # a 16-bit partition would not fit one compact table any more
     p = P(8 * 10**9, 8 * 10**9)
     assert (p.passes, p.bits1, p.bits2) == (2, 9, 9)    # never plans a 10-bit pass: the bucket join chunks instead
     assert P(10**9, 5).passes == 0

@@ -21,6 +21,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <mutex>
+#include <type_traits>
 #include <vector>
 
 namespace {
@@ -627,7 +628,8 @@ dev_scatter_wc(const Tup *__restrict__ in, Tup *__restrict__ out, const u64 *__r
     u32 *cnt = reinterpret_cast<u32 *>(LB + nbins);
     u32 *P = cnt + nbins;                                                    // sexcl | heads << 16 | (g0 & 7) << 20
     u32 *LO = P + nbins;                                                     // first valid slot of the carried line
-    u32 *mtot = LO + nbins;                                                  // staged tuples of this tile
+    u32 *T = LO + nbins;                                                     // staged slots below T[d] are whole lines of digit d
+    u32 *mtot = T + nbins;                                                   // staged tuples of this tile
     u32 *wsc = mtot + 4;                                                     // THREADS/64 wave totals
 
     u64 beg, end;
@@ -661,13 +663,16 @@ dev_scatter_wc(const Tup *__restrict__ in, Tup *__restrict__ out, const u64 *__r
             if (i < ntile) t[k] = tp[i];
         }
     };
-    auto process = [&](Tup (&t)[WC_TPT], u64 tb) {
-        const u32 ntile = (end - tb < (u64)TILE) ? (u32)(end - tb) : (u32)TILE;
-        u32 rk[WC_TPT];
+    // FULL: the tile has TILE tuples (every tile of a unit but its last): no per-tuple range checks
+    auto process = [&](Tup (&t)[WC_TPT], u64 tb, auto full_tag) {
+        constexpr bool FULL = decltype(full_tag)::value;
+        const u32 ntile = FULL ? (u32)TILE : (u32)(end - tb);
+        u32 rk[WC_TPT], dg[WC_TPT];
 #pragma unroll
         for (int k = 0; k < WC_TPT; k++) {
             const u32 i = k * THREADS + tid;
-            if (i < ntile) rk[k] = atomicAdd(&cnt[(u32)(t[k].payload >> shift) & mask], 1u);
+            dg[k] = (u32)(t[k].payload >> shift) & mask;
+            if (FULL || i < ntile) rk[k] = atomicAdd(&cnt[dg[k]], 1u);
         }
         __syncthreads();                                                     // B1: counts complete
         {   // plan of this tile, one digit per thread (nbins <= 512 <= THREADS): staged count m per digit,
@@ -694,6 +699,9 @@ dev_scatter_wc(const Tup *__restrict__ in, Tup *__restrict__ out, const u64 *__r
                 else LB[b] = ~0ull;
                 gnext[b] = e;
                 cnt[b] = 0;
+                // staged slot i of digit b has global index (a - sx) + i; it is part of a whole line iff that is below the
+                // last line boundary (e & ~7): i < sx + ((e & ~7) - a), when any line was crossed at all
+                T[b] = (crossed && (e & ~7ull) > a) ? sx + (u32)((e & ~7ull) - a) : sx;
                 if (b == nbins - 1) *mtot = sx + m;
             }
         }
@@ -701,11 +709,12 @@ dev_scatter_wc(const Tup *__restrict__ in, Tup *__restrict__ out, const u64 *__r
 #pragma unroll
         for (int k = 0; k < WC_TPT; k++) {
             const u32 i = k * THREADS + tid;
-            if (i < ntile) {
-                const u32 d = (u32)(t[k].payload >> shift) & mask;
+            if (FULL || i < ntile) {
+                const u32 d = dg[k];
                 const u32 p = P[d], heads = (p >> 16) & 0xfffu;
-                if (rk[k] < heads) cb[d * 8 + (p >> 28) + rk[k]] = t[k];
-                else tile[(p & 0xffffu) + rk[k] - heads] = t[k];
+                // one LDS store with a selected address (cb and tile are one array: cb = tile + TILE)
+                const u32 slot = rk[k] < heads ? (u32)TILE + d * 8 + (p >> 28) + rk[k] : (p & 0xffffu) + rk[k] - heads;
+                tile[slot] = t[k];
             }
         }
         __syncthreads();                                                     // D: cb heads + staging complete
@@ -722,8 +731,7 @@ dev_scatter_wc(const Tup *__restrict__ in, Tup *__restrict__ out, const u64 *__r
             if (i < mt) {
                 const Tup v = tile[i];
                 const u32 d = (u32)(v.payload >> shift) & mask;
-                const u64 g = A[d] + i;
-                if (g < (gnext[d] & ~7ull)) out[g] = v;                       // whole lines [a, b)
+                if (i < T[d]) out[A[d] + i] = v;                              // whole lines [a, b)
                 else keep |= 1u << k;                                         // tail [b, e): carried on
             }
         }
@@ -747,12 +755,12 @@ dev_scatter_wc(const Tup *__restrict__ in, Tup *__restrict__ out, const u64 *__r
     while (cur < end) {
         u64 nxt = cur + TILE;
         if (nxt < end) load_tile(tb_, nxt);
-        process(ta, cur);
+        if (nxt <= end) process(ta, cur, std::true_type{}); else process(ta, cur, std::false_type{});
         cur = nxt;
         if (cur >= end) break;
         nxt = cur + TILE;
         if (nxt < end) load_tile(ta, nxt);
-        process(tb_, cur);
+        if (nxt <= end) process(tb_, cur, std::true_type{}); else process(tb_, cur, std::false_type{});
         cur = nxt;
     }
     __syncthreads();
@@ -1574,7 +1582,7 @@ size_t part_lds_bytes(int bits)
 static size_t wc_lds_bytes(int bits, int threads)
 {
     const size_t nbins = (size_t)1 << bits;
-    return (size_t)threads * WC_TPT * 16 + nbins * (128 + 8 + 8 + 8 + 4 + 4 + 4) + 16 + (size_t)(threads / 64) * 4;
+    return (size_t)threads * WC_TPT * 16 + nbins * (128 + 8 + 8 + 8 + 4 + 4 + 4 + 4) + 16 + (size_t)(threads / 64) * 4;
 }
 
 static int wc_threads_for(int bits)

@@ -69,6 +69,7 @@ struct rhj_ctx {
     u32 cur_probe_split = 0;
     // pinned host landing zone of the small-join path: 64-byte header {count}, then up to 128 KiB of result pairs
     unsigned char *h_land = nullptr;
+    unsigned char *h_land_dev = nullptr;   // the same memory as the device addresses it
     // tuning / test knobs (rhj_set_option)
     int opt_big_tables = -1;           // -1: by average build partition size, 0: never, 1: always use an oversized-partition kernel
     int opt_big_kernel = -1;           // -1: automatic, JK_BKT_BIG: never the compact-table kernel
@@ -767,12 +768,11 @@ namespace {
 
 // rhj_join for small inputs (the 94 joins of small.work are <= 43 K tuples).  Every asynchronous operation
 // costs 5-10 us of latency on this platform whatever its size (measured: 2 H2D + memset + kernel + 2 D2H = 48 us for a
-// 3754 x 14368 join whose kernel runs ~10 us), so the sequence is cut to FOUR operations and one host synchronisation:
-//   H2D R, H2D S, ONE kernel (k_join_bkt DIRECT), ONE D2H of {result count | pairs} -- the count lives in a 64-byte
-//   header in front of the pairs in HBM, and the optimistic number of pairs (a foreign-key join yields about
-//   max(|R|,|S|); at most 1 MiB) travels with it into pinned memory, from where one memcpy fills the exact-size page;
-//   whatever a larger result has beyond that is fetched from HBM straight into the page.
-// The header is zeroed for the NEXT call after this one has read it (off the critical path).
+// 3754 x 14368 join whose kernel runs ~10 us), so the sequence is cut to THREE operations and one host synchronisation:
+//   H2D R, H2D S, ONE kernel (k_join_bkt DIRECT) that stores the pairs into HBM AND, the first MiB of them, straight into
+//   pinned host memory, and whose last workgroup publishes the result count there and zeroes the device counters for the
+//   next call.  One memcpy fills the exact-size page; what a larger result has beyond the first MiB is fetched from HBM
+//   straight into the page (no second run: the pairs have the same positions in both places).
 constexpr size_t LAND_BYTES = (size_t)1 << 20;
 
 int join_small_host(rhj_ctx *ctx, const rhj_tuple *R, u64 nR, const rhj_tuple *S, u64 nS, void **out_page, u64 *out_count)
@@ -783,10 +783,13 @@ int join_small_host(rhj_ctx *ctx, const rhj_tuple *R, u64 nR, const rhj_tuple *S
         return std::chrono::duration<double, std::micro>(b - a).count();
     };
     const auto t0 = now();
-    const u64 guess = (nR > nS ? nR : nS) + 1024;
+    const u64 guess = (nR > nS ? nR : nS) + 1024, landcap = LAND_BYTES / 16;
     RHJCHK(ensure(ctx, ctx->in_R, (size_t)nR * 16));
     RHJCHK(ensure(ctx, ctx->in_S, (size_t)nS * 16));
-    if (!ctx->h_land) HIPCHK(ctx, hipHostMalloc((void **)&ctx->h_land, 64 + LAND_BYTES, hipHostMallocDefault));
+    if (!ctx->h_land) {
+        HIPCHK(ctx, hipHostMalloc((void **)&ctx->h_land, 64 + LAND_BYTES, hipHostMallocDefault));
+        HIPCHK(ctx, hipHostGetDevicePointer((void **)&ctx->h_land_dev, ctx->h_land, 0));
+    }
     if (ctx->small_out.cap < 64 + (size_t)guess * 16) {
         RHJCHK(ensure(ctx, ctx->small_out, 64 + (size_t)guess * 16));
         ctx->small_hdr_clean = false;
@@ -796,27 +799,29 @@ int join_small_host(rhj_ctx *ctx, const rhj_tuple *R, u64 nR, const rhj_tuple *S
     ctx->last.passes = 0;
     u64 count = 0, landed = 0;
     for (int attempt = 0; attempt < 2; attempt++) {
+        // device buffer: {64-byte header: [0] count, [8] finished workgroups | pairs}; the first MiB of pairs and the count
+        // land in pinned host memory as well, written by the kernel itself
         unsigned char *d_hdr = (unsigned char *)ctx->small_out.p;
         const u64 dcap = (ctx->small_out.cap - 64) / 16;
         if (!ctx->small_hdr_clean) HIPCHK(ctx, hipMemsetAsync(d_hdr, 0, 64, ctx->stream));
         ctx->small_hdr_clean = false;
         {
             Span s(ctx, RHJ_K_JOIN);
-            launch_join_direct(ctx->stream, ctx->in_R.p, nR, ctx->in_S.p, nS, d_hdr + 64, dcap, (u64 *)d_hdr);
+            launch_join_direct(ctx->stream, ctx->in_R.p, nR, ctx->in_S.p, nS, d_hdr + 64, dcap, (u64 *)d_hdr,
+                               (u64 *)ctx->h_land_dev, (u32 *)(d_hdr + 8), ctx->h_land_dev + 64, landcap);
         }
         RHJCHK(check_launch(ctx, "direct join"));
-        landed = attempt == 0 ? guess : dcap;                             // pairs that travel with the count
-        if (landed > dcap) landed = dcap;
-        if (landed * 16 > LAND_BYTES) landed = LAND_BYTES / 16;
         const auto t1 = now();
-        HIPCHK(ctx, hipMemcpyAsync(ctx->h_land, d_hdr, 64 + (size_t)landed * 16, hipMemcpyDeviceToHost, ctx->stream));
         HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
-        count = *(const u64 *)ctx->h_land;
-        if (trace) fprintf(stderr, "[small join %llu x %llu -> %llu] enqueue %.1f  d2h+sync %.1f us\n", (unsigned long long)nR,
+        ctx->small_hdr_clean = true;                                      // the last workgroup zeroed the counters
+        count = *(volatile const u64 *)ctx->h_land;
+        landed = dcap < landcap ? dcap : landcap;
+        if (trace) fprintf(stderr, "[small join %llu x %llu -> %llu] enqueue %.1f  sync %.1f us\n", (unsigned long long)nR,
                            (unsigned long long)nS, (unsigned long long)count, us(t0, t1), us(t1, now()));
-        if (count <= dcap) break;                                         // every pair is in HBM
+        if (count <= dcap) break;                                         // every pair is in HBM (and the first MiB on the host)
         if (attempt == 1) return fail(ctx, RHJ_E_HIP, "result count changed between join phases");
         RHJCHK(ensure(ctx, ctx->small_out, 64 + (size_t)count * 16));     // more pairs than the buffer holds: exact size known now
+        ctx->small_hdr_clean = false;
     }
     unsigned char *page = nullptr;
     if (count) {
@@ -832,8 +837,6 @@ int join_small_host(rhj_ctx *ctx, const rhj_tuple *R, u64 nR, const rhj_tuple *S
             if (e != hipSuccess) { free(page); return fail(ctx, RHJ_E_HIP, std::string("result copy: ") + hipGetErrorString(e)); }
         }
     }
-    // header of the next small join: zeroed behind this one
-    if (hipMemsetAsync(ctx->small_out.p, 0, 64, ctx->stream) == hipSuccess) ctx->small_hdr_clean = true;
     *out_page = page;                                                     // nullptr when nothing matched (Result::isEmpty)
     *out_count = count;
     return RHJ_OK;

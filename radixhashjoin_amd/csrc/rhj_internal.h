@@ -63,7 +63,8 @@ void launch_join(hipStream_t st, const void *d_R, const u64 *d_startR, const voi
                  const JoinTask *d_tasks, const u32 *d_ntasks, u32 grid, int radix_bits,
                  void *d_out, u64 out_capacity, u64 *d_out_count, int kind);
 void launch_join_direct(hipStream_t st, const void *d_R, u64 nR, const void *d_S, u64 nS, void *d_out, u64 out_capacity,
-                        u64 *d_out_count);
+                        u64 *d_out_count, u64 *host_count = nullptr, u32 *d_done = nullptr, void *host_out = nullptr,
+                        u64 host_cap = 0);
 void launch_checksum(hipStream_t st, const void *d_pairs, u64 n, u64 *d_sum);
 void launch_generate(hipStream_t st, int kind, void *d_out, u64 n, u64 row0, u64 D, u64 seed, double theta);
 void launch_expected_pkfk(hipStream_t st, const void *d_S, u64 n, u64 *d_sum);

@@ -940,7 +940,12 @@ __device__ __forceinline__ u32 bj_bucket(u64 v, int radix_bits)
 // DIRECT: no task list -- the inputs are ONE unpartitioned pair of relations and workgroup b probes tuples
 // [b * dsplit, (b+1) * dsplit) of the probe side against the whole build side (small joins: the launch sequence
 // k_part_max / k_make_tasks / task-list read would cost more than the join itself).
-struct DirectJoin { u32 nb, np, build_is_S, split; };
+// host_count / done (optional): the LAST workgroup to finish copies the result count to pinned host memory and resets the
+// device counters for the next call -- with the pairs written straight into pinned host memory too, a small join needs no
+// device-to-host copy and no memset at all (H2D, H2D, kernel, synchronise).
+// host_out / host_cap: the first host_cap pairs are ALSO stored in pinned host memory (same positions as in `out`), so a
+// result that outgrows the landing zone needs no second run: the rest is fetched from `out`.
+struct DirectJoin { u32 nb, np, build_is_S, split; u64 *host_count; u32 *done; Pair *host_out; u64 host_cap; };
 
 template <int THREADS, int CHUNK, int BBITS, int EPT, bool DIRECT>
 __global__ void __launch_bounds__(THREADS, 4)
@@ -1111,6 +1116,7 @@ k_join_bkt(const Tup *__restrict__ R, const Tup *__restrict__ S, const JoinTask 
                                     if (build_is_S) { pr.r = p[k].key; pr.s = rids[j]; }   // orderFlag, Result.cpp:64-68
                                     else            { pr.r = rids[j]; pr.s = p[k].key; }
                                     out[o] = pr;
+                                    if (DIRECT && o < dj.host_cap) dj.host_out[o] = pr;
                                 }
                                 o++;
                             }
@@ -1134,6 +1140,7 @@ k_join_bkt(const Tup *__restrict__ R, const Tup *__restrict__ S, const JoinTask 
                                     if (build_is_S) { pr.r = pkey; pr.s = rids[j + lane]; }
                                     else            { pr.r = rids[j + lane]; pr.s = pkey; }
                                     out[dst] = pr;
+                                    if (DIRECT && dst < dj.host_cap) dj.host_out[dst] = pr;
                                 }
                                 ob += (u64)__popcll(bal);
                             }
@@ -1144,6 +1151,17 @@ k_join_bkt(const Tup *__restrict__ R, const Tup *__restrict__ S, const JoinTask 
             // wtot / gres are rewritten only after the next tile's first barrier: safe without another one
         }
         __syncthreads();         // the table is rebuilt by the next chunk
+    }
+    if (DIRECT && dj.host_count != nullptr) {
+        __syncthreads();                                                     // every store / atomic of this workgroup has been issued
+        if (tid == 0) {
+            __threadfence_system();                                          // ... and is visible before `done` says so
+            if (atomicAdd(dj.done, 1u) == gridDim.x - 1) {                   // last workgroup of the launch
+                __threadfence_system();
+                *dj.host_count = atomicExch(out_count, 0ull);                // publish, and leave the counters zeroed
+                *dj.done = 0;
+            }
+        }
     }
 }
 
@@ -1872,10 +1890,14 @@ void launch_join(hipStream_t st, const void *d_R, const u64 *d_startR, const voi
 
 // Unpartitioned join of two small relations in ONE launch: build side = S when nR >= nS (JobScheduler.cpp:187).
 void launch_join_direct(hipStream_t st, const void *d_R, u64 nR, const void *d_S, u64 nS, void *d_out, u64 out_capacity,
-                        u64 *d_out_count)
+                        u64 *d_out_count, u64 *host_count, u32 *d_done, void *host_out, u64 host_cap)
 {
     allow_big_lds();
     DirectJoin dj;
+    dj.host_count = host_count;
+    dj.done = d_done;
+    dj.host_out = (Pair *)host_out;
+    dj.host_cap = host_out ? host_cap : 0;
     dj.build_is_S = nR >= nS ? 1u : 0u;
     dj.nb = (u32)(dj.build_is_S ? nS : nR);
     dj.np = (u32)(dj.build_is_S ? nR : nS);

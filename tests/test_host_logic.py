@@ -32,3 +32,24 @@ def test_join_cli_fails_loudly_without_gpu():
     r = subprocess.run([os.path.join(HOST, "join_gpu")], input=stdin, cwd=gold, capture_output=True, timeout=120)
     assert r.returncode != 0
     assert b"rhj_init failed" in r.stderr
+
+
+def test_balanced_owner_cuts():
+    """radixhashjoin_amd.sharded.balanced_cuts: contiguous class ranges of near-equal weight, computed by every
+    rank from the same all-gathered histogram"""
+    from radixhashjoin_amd.sharded import balanced_cuts
+    assert balanced_cuts([1] * 16, 4) == [0, 4, 8, 12, 16]
+    assert balanced_cuts([10, 1, 1, 1, 1, 1, 1, 1], 2) == [0, 1, 8]              # the hot class alone is more than half
+    c = balanced_cuts([0, 0, 0, 5, 0, 0], 3)
+    assert c[0] == 0 and c[-1] == 6 and c == sorted(c)                           # ranges may be empty, never reversed
+    import random
+    rng = random.Random(3)
+    for world in (2, 3, 4, 8):
+        w = [rng.randint(0, 1000) for _ in range(256)]
+        w[17] = 20_000                                                           # one hot class
+        cuts = balanced_cuts(w, world)
+        assert len(cuts) == world + 1 and cuts[0] == 0 and cuts[-1] == 256 and cuts == sorted(cuts)
+        loads = [sum(w[cuts[r]:cuts[r + 1]]) for r in range(world)]
+        assert sum(loads) == sum(w)
+        # no rank exceeds the mean by more than the largest single class (a class cannot be split)
+        assert max(loads) <= sum(w) / world + max(w)

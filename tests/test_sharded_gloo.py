@@ -33,6 +33,11 @@ class OracleEngine:
         d_out.numpy()[:n] = a[order]
         d_part_start.numpy()[:] = np.concatenate([[0], np.cumsum(np.bincount(dig, minlength=1 << bits))])
 
+    def histogram(self, d_rel, n, shift, bits, d_hist):
+        a = self._np(d_rel, n)
+        dig = ((a[:, 1].astype(np.uint64) >> np.uint64(shift)) & np.uint64((1 << bits) - 1)).astype(np.int64)
+        d_hist.numpy()[:] = np.bincount(dig, minlength=1 << bits)
+
     def partition(self, d_in, n, bits1, bits2, d_out, d_part_start):
         # layout documented in include/rhj.h: pass-1 digit major, pass-2 digit minor
         a = self._np(d_in, n)

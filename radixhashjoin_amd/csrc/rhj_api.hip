@@ -5,6 +5,7 @@
 #include "../../include/rhj.h"
 #include "rhj_internal.h"
 
+#include <atomic>
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
@@ -740,6 +741,7 @@ struct PagePrefault {
     unsigned char *page = nullptr;
     size_t pairs = 0;
     std::vector<std::thread> workers;
+    std::atomic<bool> stop{false};         // drop(): the result turned out empty / too large -- stop touching at once
     void start(size_t npairs)
     {
         const size_t bytes = 8 + npairs * 16;
@@ -754,11 +756,12 @@ struct PagePrefault {
         for (int t = 0; t < nt; t++)
             workers.emplace_back([=] {
                 const size_t from = bytes / nt * t, to = t + 1 == nt ? bytes : bytes / nt * (t + 1);
-                for (size_t o = from; o < to; o += 4096) ((volatile unsigned char *)page)[o] = 0;
+                for (size_t o = from; o < to && !stop.load(std::memory_order_relaxed); o += 4096)
+                    ((volatile unsigned char *)page)[o] = 0;
             });
     }
     void wait() { for (std::thread &w : workers) w.join(); workers.clear(); }
-    void drop() { wait(); free(page); page = nullptr; pairs = 0; }
+    void drop() { stop.store(true); wait(); free(page); page = nullptr; pairs = 0; }
     ~PagePrefault() { wait(); }
 };
 

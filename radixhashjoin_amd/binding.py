@@ -57,6 +57,7 @@ SYMBOLS = {
     "rhj_set_stream": (C.c_int, [_vp, _vp]),
     "rhj_set_profiling": (C.c_int, [_vp, C.c_int]),
     "rhj_set_option": (C.c_int, [_vp, C.c_char_p, C.c_int64]),
+    "rhj_get_info": (C.c_int, [_vp, C.c_char_p, C.POINTER(C.c_int64)]),
     "rhj_get_timings": (C.c_int, [_vp, _P(Timings)]),
     "rhj_sync": (C.c_int, [_vp]),
     "rhj_reserve": (C.c_int, [_vp, _u64, _u64, _P(Opts)]),
@@ -203,6 +204,12 @@ class Engine:
     def set_option(self, name, value):
         """tuning / test knobs of include/rhj.h (results never depend on them)"""
         self._chk(self.lib.rhj_set_option(self.ctx, name.encode(), int(value)))
+
+    def info(self, name):
+        """what the last join did ("last.narrow", "last.join_kernel"; include/rhj.h)"""
+        v = C.c_int64(0)
+        self._chk(self.lib.rhj_get_info(self.ctx, name.encode(), C.byref(v)))
+        return v.value
 
     def set_profiling(self, on=True):
         self._chk(self.lib.rhj_set_profiling(self.ctx, 1 if on else 0))

@@ -68,12 +68,17 @@ struct rhj_ctx {
     u64 cur_nparts = 0, cur_nR = 0, cur_nS = 0;
     int cur_radix_bits = 0;
     u32 cur_probe_split = 0;
+    int last_join_kind = -1;
+    int cur_narrow = 0;                // partitions are in the narrow {payload, rowID} format (k_scatter_wcn); 2: so was the intermediate
+    DevBuf narrow_flag;                // u32: a rowID >= 2^32 met a narrow scatter -> the join re-runs in the 16-byte format
+    bool narrow_gave_up = false;       // ... and this context stops trying
     // pinned host landing zone of the small-join path: 64-byte header {count}, then up to 128 KiB of result pairs
     unsigned char *h_land = nullptr;
     unsigned char *h_land_dev = nullptr;   // the same memory as the device addresses it
     // tuning / test knobs (rhj_set_option)
     int opt_big_tables = -1;           // -1: by average build partition size, 0: never, 1: always use an oversized-partition kernel
     int opt_big_kernel = -1;           // -1: automatic, JK_BKT_BIG: never the compact-table kernel
+    int opt_narrow = -1;               // -1: automatic (RHJ_NARROW env: 0, 1 = last pass only, 2), 0: never, 1 / 2: that level
 };
 
 namespace {
@@ -348,7 +353,8 @@ int run_pass_pair(rhj_ctx *ctx, const void *d_R, u64 nR, void *outR, u64 *psR, c
 
 // Two passes with ONE histogram read (k_hist2d_units): used when both passes fit the write-combining scatter
 // and b1 + b2 <= 16.  Pass-2 units = pieces of each pass-1 bucket written by groups of pass-1 units.
-int partition_relation_fused(rhj_ctx *ctx, const void *d_in, u64 n, int b1, int b2, void *d_out, u64 *d_ps)
+// narrow: 0 = 16-byte tuples throughout; 1 = pass 2 writes the narrow format (for the compact-table join); 2 = pass 1 too
+int partition_relation_fused(rhj_ctx *ctx, const void *d_in, u64 n, int b1, int b2, void *d_out, u64 *d_ps, int narrow = 0)
 {
     // 1024 pass-1 units instead of 2048: every unit flushes a 2^(b1+b2)-bin table, and the scatter does not care
     // ([measured] at 10^9 tuples: histogram 2.54 against 2.74 ms, scatter within noise)
@@ -387,7 +393,11 @@ int partition_relation_fused(rhj_ctx *ctx, const void *d_in, u64 n, int b1, int 
     }
     {
         Span s(ctx, RHJ_K_SCATTER);
-        launch_scatter_units(ctx->stream, d_in, ctx->part_tmp.p, g1, seg0, unit_start1, (const u64 *)ctx->unit_base.p);
+        if (narrow == 2)
+            launch_scatter_units_narrow(ctx->stream, d_in, ctx->part_tmp.p, n, g1, seg0, unit_start1, (const u64 *)ctx->unit_base.p,
+                                        (u32 *)ctx->narrow_flag.p);
+        else
+            launch_scatter_units(ctx->stream, d_in, ctx->part_tmp.p, g1, seg0, unit_start1, (const u64 *)ctx->unit_base.p);
     }
     {
         Span s(ctx, RHJ_K_AUX);
@@ -403,8 +413,12 @@ int partition_relation_fused(rhj_ctx *ctx, const void *d_in, u64 n, int b1, int 
     }
     {
         Span s(ctx, RHJ_K_SCATTER);
-        launch_scatter_ranges(ctx->stream, ctx->part_tmp.p, d_out, units2, b1, b2, (const u64 *)ctx->unit_base.p,
-                              (const u64 *)ctx->grp_rng.p);
+        if (narrow)
+            launch_scatter_ranges_narrow(ctx->stream, ctx->part_tmp.p, narrow == 2, d_out, n, units2, b1, b2,
+                                         (const u64 *)ctx->unit_base.p, (const u64 *)ctx->grp_rng.p, (u32 *)ctx->narrow_flag.p);
+        else
+            launch_scatter_ranges(ctx->stream, ctx->part_tmp.p, d_out, units2, b1, b2, (const u64 *)ctx->unit_base.p,
+                                  (const u64 *)ctx->grp_rng.p);
     }
     return check_launch(ctx, "fused two-pass partition");
 }
@@ -423,6 +437,40 @@ int partition_relation(rhj_ctx *ctx, const void *d_in, u64 n, int passes, int b1
     return run_pass(ctx, ctx->part_tmp.p, d_out, n, (const u64 *)ctx->ps_1.p, 1u << b1, b1, b2, d_ps);
 }
 
+// Which bucket-join kernel a partitioned join runs (JoinKernel).
+// Average build partition larger than one 4224-tuple table (an explicit plan with too few bits, or more than 2^30
+// tuples): the compact-table kernel when the plan removed enough payload bits for 48-bit keys, else 8448-tuple
+// chunks.  The compact-table kernel keeps a task's probe rowIDs in registers, so a task is at most that many tuples.
+int choose_join_kind(const rhj_ctx *ctx, u64 nR, u64 nS, u64 nparts, int radix_bits)
+{
+    const u64 nbuild = nR < nS ? nR : nS;
+    if (!(ctx->opt_big_tables == 1 || (ctx->opt_big_tables < 0 && nbuild / nparts > (u64)BJ_CHUNK))) return JK_BKT;
+    if (radix_bits < join_ct_min_radix_bits() || ctx->opt_big_kernel == JK_BKT_BIG) return JK_BKT_BIG;
+    if (ctx->opt_big_kernel == JK_CT || ctx->opt_big_kernel == JK_CT_HALF) return ctx->opt_big_kernel;
+    // the compact-table kernel at half size (two workgroups per CU) while the average partition fits its table
+    // AND its 8192-tuple probe tasks (a partition cut into two tasks builds its table twice)
+    const u64 nprobe = nR < nS ? nS : nR;
+    const bool half = nbuild / nparts <= (u64)join_table_tuples(JK_CT_HALF) * 15 / 16 &&
+                      nprobe / nparts <= (u64)join_probe_split(JK_CT_HALF) * 15 / 16;
+    return half ? JK_CT_HALF : JK_CT;
+}
+
+// The narrow intermediate format applies to the planned large case: fused two-pass plan, compact-table join, rowIDs
+// that can be 32 bits.  Returns the level (0 = not at all).
+int narrow_level(const rhj_ctx *ctx, u64 nR, u64 nS, const rhj_opts &plan)
+{
+    static const int env = getenv("RHJ_NARROW") ? atoi(getenv("RHJ_NARROW")) : 2;
+    const int want = ctx->opt_narrow >= 0 ? ctx->opt_narrow : env;
+    if (want <= 0 || ctx->narrow_gave_up || plan.passes != 2 || !fused_two_pass_ok(plan.bits1, plan.bits2)) return 0;
+    if (!narrow_pass_ok(plan.bits1) || !narrow_pass_ok(plan.bits2)) return 0;
+    const u64 lo = nR < nS ? nR : nS, hi = nR < nS ? nS : nR;
+    if (lo < NARROW_MIN_TUPLES || hi >= ((u64)1 << 32)) return 0;
+    const int tb = plan.bits1 + plan.bits2;
+    const int kind = choose_join_kind(ctx, nR, nS, (u64)1 << tb, tb);
+    if (kind != JK_CT && kind != JK_CT_HALF) return 0;
+    return want >= 2 ? 2 : 1;
+}
+
 // Small unpartitioned joins run as ONE launch without a task list (k_join_bkt DIRECT).
 bool is_direct(const rhj_ctx *ctx, u64 nparts, u64 nR, u64 nS)
 {
@@ -439,6 +487,12 @@ int partition_phase(rhj_ctx *ctx, const void *d_R, u64 nR, const void *d_S, u64 
     ctx->last.passes = plan.passes;
     ctx->last.bits1 = plan.bits1;
     ctx->last.bits2 = plan.bits2;
+    ctx->cur_narrow = narrow_level(ctx, nR, nS, plan);
+    if (ctx->cur_narrow) {
+        RHJCHK(ensure(ctx, ctx->narrow_flag, 64));
+        Span s(ctx, RHJ_K_AUX);
+        HIPCHK(ctx, hipMemsetAsync(ctx->narrow_flag.p, 0, 64, ctx->stream));
+    }
     if (plan.passes == 0) {
         RHJCHK(ensure(ctx, ctx->ps_R, 64));
         RHJCHK(ensure(ctx, ctx->ps_S, 64));
@@ -458,7 +512,10 @@ int partition_phase(rhj_ctx *ctx, const void *d_R, u64 nR, const void *d_S, u64 
         RHJCHK(ensure(ctx, ctx->ps_S, (np + 1) * 8));
         RHJCHK(ensure(ctx, ctx->part_R, (size_t)(nR ? nR : 1) * 16));
         RHJCHK(ensure(ctx, ctx->part_S, (size_t)(nS ? nS : 1) * 16));
-        if (plan.passes == 1 && plan.bits1 <= PASS_PAIR_MAX_BITS) {
+        if (ctx->cur_narrow) {
+            RHJCHK(partition_relation_fused(ctx, d_R, nR, plan.bits1, plan.bits2, ctx->part_R.p, (u64 *)ctx->ps_R.p, ctx->cur_narrow));
+            RHJCHK(partition_relation_fused(ctx, d_S, nS, plan.bits1, plan.bits2, ctx->part_S.p, (u64 *)ctx->ps_S.p, ctx->cur_narrow));
+        } else if (plan.passes == 1 && plan.bits1 <= PASS_PAIR_MAX_BITS) {
             RHJCHK(run_pass_pair(ctx, d_R, nR, ctx->part_R.p, (u64 *)ctx->ps_R.p, d_S, nS, ctx->part_S.p, (u64 *)ctx->ps_S.p,
                                  plan.bits1));
         } else {
@@ -477,27 +534,13 @@ int partition_phase(rhj_ctx *ctx, const void *d_R, u64 nR, const void *d_S, u64 
 
 // Join phase on explicit partitioned inputs.  Synchronises to read the exact result count.
 int join_phase_on(rhj_ctx *ctx, const void *d_Rp, const u64 *d_psR, u64 nR, const void *d_Sp, const u64 *d_psS,
-                  u64 nS, u64 nparts, int radix_bits, u32 probe_split, void *d_out, u64 cap, u64 *out_count)
+                  u64 nS, u64 nparts, int radix_bits, u32 probe_split, void *d_out, u64 cap, u64 *out_count, bool narrow = false)
 {
     if (probe_split == 0) probe_split = 32768;
     // a task addresses its build range with 32 bits; k_make_tasks reports any partition whose build side is larger
     // (counters[5], checked below) whatever the plan
-    // Average build partition larger than one 4224-tuple table (an explicit plan with too few bits, or more than 2^30
-    // tuples): the compact-table kernel when the plan removed enough payload bits for 48-bit keys, else 8448-tuple
-    // chunks.  The compact-table kernel keeps a task's probe rowIDs in registers, so a task is at most that many tuples.
-    const u64 nbuild = nR < nS ? nR : nS;
-    int kind = JK_BKT;
-    if (ctx->opt_big_tables == 1 || (ctx->opt_big_tables < 0 && nbuild / nparts > (u64)BJ_CHUNK)) {
-        if (radix_bits < join_ct_min_radix_bits() || ctx->opt_big_kernel == JK_BKT_BIG) kind = JK_BKT_BIG;
-        else if (ctx->opt_big_kernel == JK_CT || ctx->opt_big_kernel == JK_CT_HALF) kind = ctx->opt_big_kernel;
-        else {  // the compact-table kernel at half size (two workgroups per CU) while the average partition fits its table
-                // AND its 8192-tuple probe tasks (a partition cut into two tasks builds its table twice)
-            const u64 nprobe = nR < nS ? nS : nR;
-            const bool half = nbuild / nparts <= (u64)join_table_tuples(JK_CT_HALF) * 15 / 16 &&
-                              nprobe / nparts <= (u64)join_probe_split(JK_CT_HALF) * 15 / 16;
-            kind = half ? JK_CT_HALF : JK_CT;
-        }
-    }
+    const int kind = choose_join_kind(ctx, nR, nS, nparts, radix_bits);
+    if (narrow && kind != JK_CT && kind != JK_CT_HALF) return fail(ctx, RHJ_E_INVALID, "narrow partitions need the compact-table join");
     if (join_probe_split(kind) && probe_split > join_probe_split(kind)) probe_split = join_probe_split(kind);
     const u64 max_tasks64 = nparts + (nR + nS) / probe_split + 1;
     if (max_tasks64 > 0x7fffffffull) return fail(ctx, RHJ_E_INVALID, "too many join tasks");
@@ -510,6 +553,7 @@ int join_phase_on(rhj_ctx *ctx, const void *d_Rp, const u64 *d_psR, u64 nR, cons
         Span s(ctx, RHJ_K_AUX);
         HIPCHK(ctx, hipMemsetAsync(ctx->counters.p, 0, 64, ctx->stream));
     }
+    ctx->last_join_kind = is_direct(ctx, nparts, nR, nS) ? -1 : kind;
     if (is_direct(ctx, nparts, nR, nS)) {
         Span s(ctx, RHJ_K_JOIN);                                     // small unpartitioned join: one launch, no task list
         launch_join_direct(ctx->stream, d_Rp, nR, d_Sp, nS, d_out, d_out ? cap : 0, d_count);
@@ -522,13 +566,18 @@ int join_phase_on(rhj_ctx *ctx, const void *d_Rp, const u64 *d_psR, u64 nR, cons
         {
             Span s(ctx, RHJ_K_JOIN);
             launch_join(ctx->stream, d_Rp, d_psR, d_Sp, d_psS, (const JoinTask *)ctx->tasks.p, d_ntasks, max_tasks,
-                        radix_bits, d_out, d_out ? cap : 0, d_count, kind);
+                        radix_bits, d_out, d_out ? cap : 0, d_count, kind,
+                        narrow ? (const u32 *)((const unsigned char *)d_Rp + narrow_k_offset(nR)) : nullptr,
+                        narrow ? (const u32 *)((const unsigned char *)d_Sp + narrow_k_offset(nS)) : nullptr);
         }
     }
     RHJCHK(check_launch(ctx, "join phase"));
     u64 host[6] = {0, 0, 0, 0, 0, 0};          // count, ntasks, max |R_k|, max |S_k|, (checksum scratch), oversized build side
+    u32 wide_rowid = 0;
     HIPCHK(ctx, hipMemcpyAsync(host, ctx->counters.p, sizeof(host), hipMemcpyDeviceToHost, ctx->stream));
+    if (narrow) HIPCHK(ctx, hipMemcpyAsync(&wide_rowid, ctx->narrow_flag.p, 4, hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    if (wide_rowid) return RHJ_RETRY_WIDE;                       // a rowID did not fit 32 bits: nothing of this run is valid
     *out_count = host[0];
     ctx->last.ntasks = (u32)(host[1] & 0xffffffffu);
     if (host[5])
@@ -540,7 +589,19 @@ int join_phase_on(rhj_ctx *ctx, const void *d_Rp, const u64 *d_psR, u64 nR, cons
 int join_phase(rhj_ctx *ctx, void *d_out, u64 cap, u64 *out_count)
 {
     return join_phase_on(ctx, ctx->cur_R, ctx->cur_psR, ctx->cur_nR, ctx->cur_S, ctx->cur_psS, ctx->cur_nS,
-                         ctx->cur_nparts, ctx->cur_radix_bits, ctx->cur_probe_split, d_out, cap, out_count);
+                         ctx->cur_nparts, ctx->cur_radix_bits, ctx->cur_probe_split, d_out, cap, out_count, ctx->cur_narrow != 0);
+}
+
+// partition + join; a run in the narrow format that met a rowID >= 2^32 is repeated in the 16-byte format
+int partition_and_join(rhj_ctx *ctx, const void *d_R, u64 nR, const void *d_S, u64 nS, const rhj_opts &plan, void *d_out,
+                       u64 cap, u64 *out_count)
+{
+    RHJCHK(partition_phase(ctx, d_R, nR, d_S, nS, plan));
+    int rc = join_phase(ctx, d_out, cap, out_count);
+    if (rc != RHJ_RETRY_WIDE) return rc;
+    ctx->narrow_gave_up = true;
+    RHJCHK(partition_phase(ctx, d_R, nR, d_S, nS, plan));
+    return join_phase(ctx, d_out, cap, out_count);
 }
 
 }  // namespace
@@ -616,7 +677,7 @@ int rhj_release_workspace(rhj_ctx *ctx)
                      &ctx->ps_1, &ctx->seg0, &ctx->unit_start, &ctx->unit_hist, &ctx->unit_base, &ctx->seg0_b,
                      &ctx->unit_start_b, &ctx->unit_hist_b, &ctx->unit_base_b, &ctx->scan_tmp_b, &ctx->tasks,
                      &ctx->counters, &ctx->out_pairs, &ctx->small_out, &ctx->hist_tmp, &ctx->scan_tmp, &ctx->hist2,
-                     &ctx->grp_rng, &ctx->unit_start2};
+                     &ctx->grp_rng, &ctx->unit_start2, &ctx->narrow_flag};
     for (DevBuf *b : all) release(*b);
     ctx->small_hdr_clean = false;
     for (auto &b : ctx->free_blocks) {
@@ -661,7 +722,21 @@ int rhj_set_option(rhj_ctx *ctx, const char *name, int64_t value)
         ctx->opt_big_kernel = (int)value;
         return RHJ_OK;
     }
+    if (n == "partition.narrow" && value >= -1 && value <= 2) {
+        ctx->opt_narrow = (int)value;
+        if (value != 0) ctx->narrow_gave_up = false;
+        return RHJ_OK;
+    }
     return fail(ctx, RHJ_E_INVALID, "rhj_set_option: unknown option or value: " + n);
+}
+
+int rhj_get_info(rhj_ctx *ctx, const char *name, int64_t *value)
+{
+    if (!ctx || !name || !value) return fail(ctx, RHJ_E_INVALID, "rhj_get_info: null argument");
+    const std::string n(name);
+    if (n == "last.narrow") { *value = ctx->cur_narrow; return RHJ_OK; }
+    if (n == "last.join_kernel") { *value = ctx->last_join_kind; return RHJ_OK; }
+    return fail(ctx, RHJ_E_INVALID, "rhj_get_info: unknown name: " + n);
 }
 
 int rhj_set_profiling(rhj_ctx *ctx, int enabled)
@@ -725,8 +800,7 @@ int rhj_join_dev(rhj_ctx *ctx, const rhj_tuple *d_R, uint64_t nR, const rhj_tupl
     if (!d_R || !d_S) return fail(ctx, RHJ_E_INVALID, "null input relation");
     rhj_opts plan;
     if (resolve_plan(nR, nS, opts, &plan) != RHJ_OK) return fail(ctx, RHJ_E_INVALID, "bad rhj_opts");
-    RHJCHK(partition_phase(ctx, d_R, nR, d_S, nS, plan));
-    RHJCHK(join_phase(ctx, d_out, d_out ? out_capacity : 0, (u64 *)out_count));
+    RHJCHK(partition_and_join(ctx, d_R, nR, d_S, nS, plan, d_out, d_out ? out_capacity : 0, (u64 *)out_count));
     if (d_out && *out_count > out_capacity) return fail(ctx, RHJ_E_OVERFLOW, "result buffer too small");
     return RHJ_OK;
 }
@@ -872,10 +946,9 @@ int rhj_join(rhj_ctx *ctx, const rhj_tuple *R, uint64_t nR, const rhj_tuple *S, 
         RHJCHK(ensure(ctx, ctx->in_S, (size_t)nS * 16));
         RHJCHK(h2d_staged(ctx, ctx->in_R.p, R, (size_t)nR * 16));
         RHJCHK(h2d_staged(ctx, ctx->in_S.p, S, (size_t)nS * 16));
-        RHJCHK(partition_phase(ctx, ctx->in_R.p, nR, ctx->in_S.p, nS, plan));
         RHJCHK(ensure(ctx, ctx->out_pairs, (size_t)cap * 16));
         u64 dcap = ctx->out_pairs.cap / 16;
-        RHJCHK(join_phase(ctx, ctx->out_pairs.p, dcap, &count));
+        RHJCHK(partition_and_join(ctx, ctx->in_R.p, nR, ctx->in_S.p, nS, plan, ctx->out_pairs.p, dcap, &count));
         if (count > dcap) {
             RHJCHK(ensure(ctx, ctx->out_pairs, (size_t)count * 16));
             dcap = ctx->out_pairs.cap / 16;

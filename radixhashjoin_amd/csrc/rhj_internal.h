@@ -61,7 +61,7 @@ void launch_make_tasks(hipStream_t st, const u64 *d_startR, const u64 *d_startS,
                        JoinTask *d_tasks, u32 *d_ntasks, u32 max_tasks, u64 *d_stats, int kind);
 void launch_join(hipStream_t st, const void *d_R, const u64 *d_startR, const void *d_S, const u64 *d_startS,
                  const JoinTask *d_tasks, const u32 *d_ntasks, u32 grid, int radix_bits,
-                 void *d_out, u64 out_capacity, u64 *d_out_count, int kind);
+                 void *d_out, u64 out_capacity, u64 *d_out_count, int kind, const u32 *d_RK = nullptr, const u32 *d_SK = nullptr);
 void launch_join_direct(hipStream_t st, const void *d_R, u64 nR, const void *d_S, u64 nS, void *d_out, u64 out_capacity,
                         u64 *d_out_count, u64 *host_count = nullptr, u32 *d_done = nullptr, void *host_out = nullptr,
                         u64 host_cap = 0);
@@ -97,5 +97,14 @@ void launch_make_group_ranges(hipStream_t st, const u64 *d_unit_base1, u32 nb1, 
                               u64 *d_rng, u32 *d_unit_start2);
 void launch_scatter_ranges(hipStream_t st, const void *d_in, void *d_out, u32 nunits, int shift, int bits,
                            const u64 *d_unit_base, const u64 *d_rng);
+// narrow intermediate format (k_scatter_wcn): payloads (u64) at offset 0 of a buffer of >= 16 n bytes, rowIDs (u32) here
+inline size_t narrow_k_offset(u64 n) { return ((size_t)n * 8 + 255) & ~(size_t)255; }
+constexpr int RHJ_RETRY_WIDE = 1000;                    // internal: join_phase saw the narrow-format overflow flag
+constexpr u64 NARROW_MIN_TUPLES = 1024;                 // 12 n + 256 <= 16 n
+bool narrow_pass_ok(int bits);
+void launch_scatter_units_narrow(hipStream_t st, const void *d_in, void *d_out, u64 n, const PassGeom &g,
+                                 const u64 *d_seg_start, const u32 *d_unit_start, const u64 *d_unit_base, u32 *d_overflow);
+void launch_scatter_ranges_narrow(hipStream_t st, const void *d_in, bool in_narrow, void *d_out, u64 n, u32 nunits, int shift,
+                                  int bits, const u64 *d_unit_base, const u64 *d_rng, u32 *d_overflow);
 size_t scan_tmp_bytes(int bits);
 size_t part_lds_bytes(int bits);

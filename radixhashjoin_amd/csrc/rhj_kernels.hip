@@ -790,6 +790,204 @@ __global__ void __launch_bounds__(THREADS) k_scatter_wc2(PassPair a, int shift, 
                             blockIdx.x);
 }
 
+// ------------------------------------------------------------------------------------------------
+// K2n: the write-combining scatter with a NARROW intermediate format (internal to a join; never seen at the C-ABI).
+// A partition pass at 10^9 tuples runs at the HBM copy rate ([measured] tools/copybench: a plain 16 B/tuple copy with
+// this kernel's shape takes as long as the scatter), so the only way down is fewer bytes: between the passes of a
+// two-pass plan and between the last pass and the join a tuple is {payload 8 B, rowID 4 B} in two arrays (rowIDs of a
+// relation of < 2^32 tuples; a larger rowID raises *overflow and the join re-runs in the 16-byte format).
+//   P[i] (u64) payloads, K[i] (u32) rowIDs, same index i as the 16-byte layout (part_start is unchanged).
+// Writes cost per 128-byte line touched, not per byte ([measured] copybench: 64 B + 32 B pieces per 8 tuples are 25 %
+// SLOWER than 128 B lines, 128 B + 64 B per 16 tuples equal, 256 B + 128 B per 32 tuples 17 % faster), so the carry
+// line of a digit is GR = 32 tuples: 2 payload lines + 1 rowID line.  Same algorithm as dev_scatter_wc with 8 -> GR;
+// staging and carry live in LDS as two arrays (8 B + 4 B per slot); one workgroup of 1024 threads per CU.
+//   IN_NARROW: the input is already narrow (pass 2 of a plan whose pass 1 wrote narrow).
+// ------------------------------------------------------------------------------------------------
+constexpr int WN_THREADS = 1024, WN_TPT = 4, WN_GR = 32, WN_MAX_BITS = 8;
+
+template <bool IN_NARROW>
+__global__ void __launch_bounds__(WN_THREADS)
+k_scatter_wcn(const Tup *__restrict__ in, const u64 *__restrict__ inP, const u32 *__restrict__ inK,
+              u64 *__restrict__ outP, u32 *__restrict__ outK, const u64 *__restrict__ seg_start,
+              const u32 *__restrict__ unit_start, u32 nseg, u64 L, int shift, int bits,
+              const u64 *__restrict__ unit_base, const u64 *__restrict__ unit_rng, u32 n_rng_units,
+              u32 *__restrict__ overflow)
+{
+    constexpr int THREADS = WN_THREADS, TPT = WN_TPT, TILE = THREADS * TPT, GR = WN_GR;
+    constexpr u64 GM = GR - 1;
+    using KeyT = typename std::conditional<IN_NARROW, u32, u64>::type;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const u32 nbins = 1u << bits, mask = nbins - 1;
+    u64 *sp = reinterpret_cast<u64 *>(smem);                                 // payloads: TILE staging slots, then nbins carry lines
+    u64 *gnext = sp + TILE + (size_t)nbins * GR;                             // next global index per digit
+    u64 *A = gnext + nbins;                                                  // staging slot i -> global index A[d] + i
+    u64 *LB = A + nbins;                                                     // carry-line flush: (line base | first slot), ~0 = none
+    u32 *sk = reinterpret_cast<u32 *>(LB + nbins);                           // rowIDs, same slot numbering as sp
+    u32 *cnt = sk + TILE + (size_t)nbins * GR;
+    u32 *P = cnt + nbins;                                                    // sexcl | heads << 16 | (g0 & GM) << 24
+    u32 *LO = P + nbins;                                                     // first valid slot of the carried line
+    u32 *T = LO + nbins;                                                     // staged slots below T[d] are whole lines of digit d
+    u32 *mtot = T + nbins;
+    u32 *wsc = mtot + 4;
+
+    const u32 u = blockIdx.x;
+    u64 beg, end;
+    if (unit_rng != nullptr) {
+        if (u >= n_rng_units) return;
+        beg = unit_rng[u];
+        end = unit_rng[u + 1];
+    } else {
+        if (u >= unit_start[nseg]) return;
+        const u32 s = find_segment(unit_start, nseg, u);
+        beg = seg_start[s] + (u64)(u - unit_start[s]) * L;
+        const u64 send = seg_start[s + 1];
+        end = (beg + L < send) ? beg + L : send;
+    }
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+
+    for (u32 b = tid; b < nbins; b += THREADS) {
+        const u64 g = unit_base[(u64)u * nbins + b];
+        gnext[b] = g;
+        LO[b] = (u32)(g & GM);
+        cnt[b] = 0;
+    }
+    __syncthreads();
+
+    u32 ovf = 0;                                                             // any rowID >= 2^32 seen (16-byte input only)
+    auto load_tile = [&](u64 (&pay)[TPT], KeyT (&key)[TPT], u64 tb) {
+        const u32 ntile = (end - tb < (u64)TILE) ? (u32)(end - tb) : (u32)TILE;
+#pragma unroll
+        for (int k = 0; k < TPT; k++) {
+            const u32 i = k * THREADS + tid;
+            if (i < ntile) {
+                if constexpr (IN_NARROW) { pay[k] = inP[tb + i]; key[k] = inK[tb + i]; }
+                else { const Tup v = in[tb + i]; pay[k] = v.payload; key[k] = v.key; }
+            }
+        }
+    };
+    auto process = [&](u64 (&pay)[TPT], KeyT (&key)[TPT], u64 tb, auto full_tag) {
+        constexpr bool FULL = decltype(full_tag)::value;
+        const u32 ntile = FULL ? (u32)TILE : (u32)(end - tb);
+        u32 rk[TPT], dg[TPT];
+#pragma unroll
+        for (int k = 0; k < TPT; k++) {
+            const u32 i = k * THREADS + tid;
+            dg[k] = (u32)(pay[k] >> shift) & mask;
+            if (FULL || i < ntile) {
+                rk[k] = atomicAdd(&cnt[dg[k]], 1u);
+                if constexpr (!IN_NARROW) ovf |= (u32)(key[k] >> 32);
+            }
+        }
+        __syncthreads();                                                     // B1: counts complete
+        {
+            const u32 b = tid;
+            u32 c = 0, m = 0;
+            u64 g0 = 0, e = 0, a = 0;
+            if (b < nbins) {
+                c = cnt[b];
+                g0 = gnext[b]; e = g0 + c; a = (g0 + GM) & ~GM;
+                m = (e >= a) ? (u32)(e - a) : 0u;
+            }
+            const u32 inc = wave_incl_scan(m, lane);
+            if (lane == 63) wsc[wave] = inc;
+            __syncthreads();                                                 // Sx: wave totals visible
+            if (b < nbins) {
+                u32 sx = inc - m;
+                for (int i = 0; i < wave; i++) sx += wsc[i];
+                const bool crossed = e >= a;
+                const u32 heads = crossed ? (u32)(a - g0) : c;               // tuples that go straight to the carry line (< GR)
+                P[b] = sx | (heads << 16) | ((u32)(g0 & GM) << 24);
+                A[b] = a - sx;
+                if (crossed && (g0 & GM)) { LB[b] = (a - GR) | LO[b]; LO[b] = 0; }
+                else LB[b] = ~0ull;
+                gnext[b] = e;
+                cnt[b] = 0;
+                T[b] = (crossed && (e & ~GM) > a) ? sx + (u32)((e & ~GM) - a) : sx;
+                if (b == nbins - 1) *mtot = sx + m;
+            }
+        }
+        __syncthreads();                                                     // S2: plan visible
+#pragma unroll
+        for (int k = 0; k < TPT; k++) {
+            const u32 i = k * THREADS + tid;
+            if (FULL || i < ntile) {
+                const u32 d = dg[k];
+                const u32 p = P[d], heads = (p >> 16) & 0xffu;
+                const u32 slot = rk[k] < heads ? (u32)TILE + d * GR + (p >> 24) + rk[k] : (p & 0xffffu) + rk[k] - heads;
+                sp[slot] = pay[k];
+                sk[slot] = (u32)key[k];
+            }
+        }
+        __syncthreads();                                                     // D: carry heads + staging complete
+        for (u32 q = tid; q < nbins * GR; q += THREADS) {                    // completed carry lines: GR lanes = 2 + 1 lines
+            const u32 d = q / GR, j = q % GR;
+            const u64 x = LB[d];
+            if (x != ~0ull && j >= (u32)(x & GM)) {
+                const u64 o = (x & ~GM) + j;
+                outP[o] = sp[TILE + q];
+                outK[o] = sk[TILE + q];
+            }
+        }
+        const u32 mt = *mtot;
+        u32 keep = 0;
+#pragma unroll
+        for (int k = 0; k < TPT; k++) {
+            const u32 i = k * THREADS + tid;
+            if (i < mt) {
+                const u64 v = sp[i];
+                const u32 d = (u32)(v >> shift) & mask;
+                if (i < T[d]) { const u64 o = A[d] + i; outP[o] = v; outK[o] = sk[i]; }      // whole lines [a, b)
+                else keep |= 1u << k;                                                       // tail [b, e): carried on
+            }
+        }
+        __syncthreads();                                                     // F: carry lines read, tails may overwrite them
+        if (keep) {
+#pragma unroll
+            for (int k = 0; k < TPT; k++) {
+                if (keep & (1u << k)) {
+                    const u32 i = k * THREADS + tid;
+                    const u64 v = sp[i];
+                    const u32 kk = sk[i];
+                    const u32 d = (u32)(v >> shift) & mask;
+                    const u32 c = (u32)TILE + d * GR + (u32)((A[d] + i) & GM);
+                    sp[c] = v;
+                    sk[c] = kk;
+                }
+            }
+        }
+    };
+
+    u64 pa[TPT], pb[TPT];
+    KeyT ka[TPT], kb[TPT];
+    u64 cur = beg;
+    if (cur < end) load_tile(pa, ka, cur);
+    while (cur < end) {
+        u64 nxt = cur + TILE;
+        if (nxt < end) load_tile(pb, kb, nxt);
+        if (nxt <= end) process(pa, ka, cur, std::true_type{}); else process(pa, ka, cur, std::false_type{});
+        cur = nxt;
+        if (cur >= end) break;
+        nxt = cur + TILE;
+        if (nxt < end) load_tile(pa, ka, nxt);
+        if (nxt <= end) process(pb, kb, cur, std::true_type{}); else process(pb, kb, cur, std::false_type{});
+        cur = nxt;
+    }
+    __syncthreads();
+    // unit end: the still incomplete line of every digit (shared with the next unit's first line)
+    for (u32 q = tid; q < nbins * GR; q += THREADS) {
+        const u32 d = q / GR, j = q % GR;
+        const u64 g = gnext[d];
+        if (j >= LO[d] && j < (u32)(g & GM)) {
+            const u64 o = (g & ~GM) + j;
+            outP[o] = sp[TILE + q];
+            outK[o] = sk[TILE + q];
+        }
+    }
+    if constexpr (!IN_NARROW) {
+        if (__ballot(ovf != 0) != 0 && lane == 0) atomicOr(overflow, 1u);
+    }
+}
+
 // d_hist[b] = d_start[b+1] - d_start[b]
 __global__ void k_diff_hist(const u64 *__restrict__ start, u64 nbins, u64 *__restrict__ hist)
 {
@@ -1215,9 +1413,32 @@ __device__ __forceinline__ u32 ct_bucket(u64 key)
 // boundaries into `stamps` (CT_NSTAMP words per workgroup); never set in production launches.
 constexpr int CT_NSTAMP = 16;
 
-template <int THREADS, int CHUNK, int BBITS, int EPT, bool STAMPS>
+// A partitioned relation as the join kernels read it: 16-byte tuples, or the narrow {payload 8 B, rowID 4 B} arrays that
+// k_scatter_wcn writes (NARROW: the build phase then reads 8 B per tuple and the rowID re-fetch 4 B instead of 16 + 16)
+template <bool NARROW> struct RelView;
+template <> struct RelView<false> {
+    typedef u64 Rid;
+    struct Both { u64 key, payload; };
+    const Tup *__restrict__ t;
+    __device__ __forceinline__ RelView at(u64 off) const { return RelView{t + off}; }
+    __device__ __forceinline__ u64 payload(u32 i) const { return t[i].payload; }
+    __device__ __forceinline__ Rid rowid(u32 i) const { return t[i].key; }
+    __device__ __forceinline__ Both both(u32 i) const { const Tup v = t[i]; return Both{v.key, v.payload}; }
+};
+template <> struct RelView<true> {
+    typedef u32 Rid;
+    struct Both { u32 key; u64 payload; };
+    const u64 *__restrict__ p;
+    const u32 *__restrict__ k;
+    __device__ __forceinline__ RelView at(u64 off) const { return RelView{p + off, k + off}; }
+    __device__ __forceinline__ u64 payload(u32 i) const { return p[i]; }
+    __device__ __forceinline__ Rid rowid(u32 i) const { return k[i]; }
+    __device__ __forceinline__ Both both(u32 i) const { return Both{k[i], p[i]}; }
+};
+
+template <int THREADS, int CHUNK, int BBITS, int EPT, bool STAMPS, bool NARROW>
 __global__ void __launch_bounds__(THREADS, 2)       // two wavefronts per SIMD: 256 registers (VGPR + AGPR) per lane
-k_join_ct(const Tup *__restrict__ R, const Tup *__restrict__ S, const JoinTask *__restrict__ tasks,
+k_join_ct(const RelView<NARROW> R, const RelView<NARROW> S, const JoinTask *__restrict__ tasks,
           const u32 *__restrict__ ntasks, int radix_bits, Pair *__restrict__ out, u64 out_capacity,
           u64 *__restrict__ out_count, u64 *__restrict__ stamps, u32 nstamp_wgs)
 {
@@ -1251,8 +1472,10 @@ k_join_ct(const Tup *__restrict__ R, const Tup *__restrict__ S, const JoinTask *
     if (blockIdx.x >= nt) return;
     const JoinTask task = tasks[blockIdx.x];
     const bool build_is_S = task.build_is_S != 0;
-    const Tup *__restrict__ B = (build_is_S ? S : R) + task.bbeg;
-    const Tup *__restrict__ P = (build_is_S ? R : S) + task.pbeg;
+    typedef typename RelView<NARROW>::Rid Rid;
+    typedef typename RelView<NARROW>::Both Both;
+    const RelView<NARROW> B = (build_is_S ? S : R).at(task.bbeg);
+    const RelView<NARROW> P = (build_is_S ? R : S).at(task.pbeg);
     const u32 nb = task.blen, np = task.plen;                                // np <= THREADS * EPT (host: probe_split)
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int rb = radix_bits;
@@ -1277,12 +1500,12 @@ k_join_ct(const Tup *__restrict__ R, const Tup *__restrict__ S, const JoinTask *
         u64 kr[BPT];
 #pragma unroll
         for (int k0 = 0; k0 < BPT; k0 += BB) {
-            Tup bt[BB];
+            u64 bt[BB];
 #pragma unroll
-            for (int k = k0; k < k0 + BB; k++) bt[k - k0] = B[cb + (k < nvb ? (u32)k * THREADS + tid : 0u)];
+            for (int k = k0; k < k0 + BB; k++) bt[k - k0] = B.payload(cb + (k < nvb ? (u32)k * THREADS + tid : 0u));
 #pragma unroll
             for (int k = k0; k < k0 + BB; k++) {
-                const u64 key = bt[k - k0].payload >> rb;
+                const u64 key = bt[k - k0] >> rb;
                 const u32 h = k < nvb ? ct_bucket<BBITS>(key) : (u32)NB + 2u, sh = (h & 1u) * 16u;   // NB + 2: a padding word
                 kr[k] = (key << 16) | ((atomicAdd(&off32[h >> 1], 1u << sh) >> sh) & 0xFFFFu);
             }
@@ -1321,17 +1544,17 @@ k_join_ct(const Tup *__restrict__ R, const Tup *__restrict__ S, const JoinTask *
         stamp();                                                             // 2: table ready
 
         // ---- probe: the task's probe tuples stream through a ring of DEPTH register tiles --------------------------
-        u64 prid[EPT];                                                       // probe rowIDs
+        Rid prid[EPT];                                                       // probe rowIDs
         u32 mi[EPT];                                                         // matches of a slot: first table position of its bucket |
                                                                              // (bit b: entry lo + b matches) << 16; 0 = none
         u32 deferred = 0;                                                    // wave-uniform: slots left to the generic loop
         u32 ctot = 0;                                                        // matches of this lane
-        Tup ring[DEPTH][PT];
+        Both ring[DEPTH][PT];
         asm volatile("" : "+v"(tid), "+v"(nv));
 #pragma unroll
         for (int t = 0; t < DEPTH && t < NT; t++)
 #pragma unroll
-            for (int s = 0; s < PT; s++) ring[t][s] = P[t * PT + s < nv ? (u32)(t * PT + s) * THREADS + tid : 0u];
+            for (int s = 0; s < PT; s++) ring[t][s] = P.both(t * PT + s < nv ? (u32)(t * PT + s) * THREADS + tid : 0u);
 #pragma unroll
         for (int t = 0; t < NT; t++) {
             u32 khi[PT], klo[PT];                                            // key << 16, to compare with an entry's upper 48 bits
@@ -1350,7 +1573,7 @@ k_join_ct(const Tup *__restrict__ R, const Tup *__restrict__ S, const JoinTask *
             if (t + DEPTH < NT) {                                            // the slot is free: next tile on its way
 #pragma unroll
                 for (int s = 0; s < PT; s++)
-                    ring[t % DEPTH][s] = P[(t + DEPTH) * PT + s < nv ? (u32)((t + DEPTH) * PT + s) * THREADS + tid : 0u];
+                    ring[t % DEPTH][s] = P.both((t + DEPTH) * PT + s < nv ? (u32)((t + DEPTH) * PT + s) * THREADS + tid : 0u);
             }
             const bool longb = __ballot(maxlen > CT_MASK_BITS) != 0;         // a long bucket somewhere: the generic loop
             if (!longb) {
@@ -1381,7 +1604,7 @@ k_join_ct(const Tup *__restrict__ R, const Tup *__restrict__ S, const JoinTask *
         while (deferred) {
             const int k = __ffs((int)deferred) - 1;
             deferred &= deferred - 1;
-            const Tup pt = P[k < nv ? (u32)k * THREADS + tid : 0u];
+            const Both pt = P.both(k < nv ? (u32)k * THREADS + tid : 0u);
             const u64 key = pt.payload >> rb;
             u32 lo = 0, hi = 0;
             if (k < nv) { const u32 h = ct_bucket<BBITS>(key); lo = off16[h]; hi = off16[h + 1]; }
@@ -1418,7 +1641,7 @@ k_join_ct(const Tup *__restrict__ R, const Tup *__restrict__ S, const JoinTask *
                     const u64 e = ent[j];
                     if ((e >> 16) == key) {
                         if (o < out_capacity) {
-                            const u64 br = B[cb + ((u32)e & 0xFFFFu)].key;
+                            const u64 br = B.rowid(cb + ((u32)e & 0xFFFFu));
                             Pair pr;
                             if (build_is_S) { pr.r = pt.key; pr.s = br; } else { pr.r = br; pr.s = pt.key; }
                             out[o] = pr;
@@ -1432,7 +1655,7 @@ k_join_ct(const Tup *__restrict__ R, const Tup *__restrict__ S, const JoinTask *
                 while (hv) {
                     const int leader = __ffsll((long long)hv) - 1;
                     hv &= hv - 1;
-                    const u64 lkey = bj_readlane64(key, leader), lprid = bj_readlane64(pt.key, leader);
+                    const u64 lkey = bj_readlane64(key, leader), lprid = bj_readlane64((u64)pt.key, leader);
                     u64 ob = bj_readlane64(o, leader);
                     const u32 l = __builtin_amdgcn_readlane(lo, leader), hh = __builtin_amdgcn_readlane(hi, leader);
                     for (u32 j = l; j < hh; j += 64) {
@@ -1442,7 +1665,7 @@ k_join_ct(const Tup *__restrict__ R, const Tup *__restrict__ S, const JoinTask *
                         const unsigned long long bal = __ballot(mt);
                         const u64 dst = ob + (u64)__popcll(bal & lt);
                         if (mt && dst < out_capacity) {
-                            const u64 br = B[cb + ((u32)e & 0xFFFFu)].key;
+                            const u64 br = B.rowid(cb + ((u32)e & 0xFFFFu));
                             Pair pr;
                             if (build_is_S) { pr.r = lprid; pr.s = br; } else { pr.r = br; pr.s = lprid; }
                             out[dst] = pr;
@@ -1459,13 +1682,13 @@ k_join_ct(const Tup *__restrict__ R, const Tup *__restrict__ S, const JoinTask *
         // take 70 more VGPRs through the probe phase (tried: the allocator spills them at their definition and the
         // build loads serialise behind the scratch stores); they are fetched again here instead, 8 of every 16 bytes of
         // a partition this CU streamed a few microseconds ago, while the barrier and the reservation go on.
-        u64 brid[BPT];
+        Rid brid[BPT];
         {
             int tq = tid0;
             asm volatile("" : "+v"(tq));
             const int nvq = nc > (u32)tq ? (int)((nc - (u32)tq + THREADS - 1) / THREADS) : 0;
 #pragma unroll
-            for (int k = 0; k < BPT; k++) brid[k] = B[cb + (k < nvq ? (u32)k * THREADS + tq : 0u)].key;
+            for (int k = 0; k < BPT; k++) brid[k] = B.rowid(cb + (k < nvq ? (u32)k * THREADS + tq : 0u));
         }
         stamp();                                                             // 5: rowID loads issued
         if (lane == 0) wtot[w] = wave_total;
@@ -1603,6 +1826,12 @@ static size_t wc_lds_bytes(int bits, int threads)
     return (size_t)threads * WC_TPT * 16 + nbins * (128 + 8 + 8 + 8 + 4 + 4 + 4 + 4) + 16 + (size_t)(threads / 64) * 4;
 }
 
+static size_t wn_lds_bytes(int bits)
+{
+    const size_t nbins = (size_t)1 << bits;
+    return ((size_t)WN_THREADS * WN_TPT + nbins * WN_GR) * 12 + nbins * (8 + 8 + 8 + 4 + 4 + 4 + 4) + 16 + (size_t)(WN_THREADS / 64) * 4;
+}
+
 static int wc_threads_for(int bits)
 {
     static const int force = getenv("RHJ_WC_THREADS") ? atoi(getenv("RHJ_WC_THREADS")) : 0;   // tuning aid
@@ -1663,13 +1892,22 @@ static void allow_big_lds()
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_join_bkt<BJ2_THREADS, BJ2_CHUNK, BJ2_BUCKET_BITS, BJ2_EPT, false>),
                               hipFuncAttributeMaxDynamicSharedMemorySize,
                               (int)bj_lds_bytes(BJ2_THREADS, BJ2_CHUNK, BJ2_BUCKET_BITS));
-    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_join_ct<CT_THREADS, CT_CHUNK, CT_BUCKET_BITS, CT_EPT, false>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_join_ct<CT_THREADS, CT_CHUNK, CT_BUCKET_BITS, CT_EPT, false, false>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)ct_lds_bytes());
-    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_join_ct<CTH_THREADS, CTH_CHUNK, CTH_BUCKET_BITS, CT_EPT, false>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_join_ct<CTH_THREADS, CTH_CHUNK, CTH_BUCKET_BITS, CT_EPT, false, false>),
                               hipFuncAttributeMaxDynamicSharedMemorySize,
                               (int)ct_lds_bytes(CTH_THREADS, CTH_CHUNK, CTH_BUCKET_BITS));
-    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_join_ct<CT_THREADS, CT_CHUNK, CT_BUCKET_BITS, CT_EPT, true>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_join_ct<CT_THREADS, CT_CHUNK, CT_BUCKET_BITS, CT_EPT, true, false>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)ct_lds_bytes());
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_join_ct<CT_THREADS, CT_CHUNK, CT_BUCKET_BITS, CT_EPT, false, true>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)ct_lds_bytes());
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_join_ct<CTH_THREADS, CTH_CHUNK, CTH_BUCKET_BITS, CT_EPT, false, true>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize,
+                              (int)ct_lds_bytes(CTH_THREADS, CTH_CHUNK, CTH_BUCKET_BITS));
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_scatter_wcn<false>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)wn_lds_bytes(WN_MAX_BITS));
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_scatter_wcn<true>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)wn_lds_bytes(WN_MAX_BITS));
     });
 }
 
@@ -1807,6 +2045,39 @@ void launch_scatter_ranges(hipStream_t st, const void *d_in, void *d_out, u32 nu
                            d_unit_base, d_rng, nunits);
 }
 
+// Narrow-format scatters (k_scatter_wcn).  A narrow relation of n tuples lives in one buffer of >= 16 n bytes: payloads
+// (u64) at offset 0, rowIDs (u32) at narrow_k_offset(n).
+bool narrow_pass_ok(int bits) { return bits >= 1 && bits <= WN_MAX_BITS; }
+
+void launch_scatter_units_narrow(hipStream_t st, const void *d_in, void *d_out, u64 n, const PassGeom &g,
+                                 const u64 *d_seg_start, const u32 *d_unit_start, const u64 *d_unit_base, u32 *d_overflow)
+{
+    if (g.max_units == 0) return;
+    allow_big_lds();
+    hipLaunchKernelGGL(k_scatter_wcn<false>, dim3(g.max_units), dim3(WN_THREADS), wn_lds_bytes(g.bits), st, (const Tup *)d_in,
+                       (const u64 *)nullptr, (const u32 *)nullptr, (u64 *)d_out,
+                       (u32 *)((unsigned char *)d_out + narrow_k_offset(n)), d_seg_start, d_unit_start, g.nseg, g.L, g.shift,
+                       g.bits, d_unit_base, (const u64 *)nullptr, 0u, d_overflow);
+}
+
+void launch_scatter_ranges_narrow(hipStream_t st, const void *d_in, bool in_narrow, void *d_out, u64 n, u32 nunits, int shift,
+                                  int bits, const u64 *d_unit_base, const u64 *d_rng, u32 *d_overflow)
+{
+    if (nunits == 0) return;
+    allow_big_lds();
+    u64 *oP = (u64 *)d_out;
+    u32 *oK = (u32 *)((unsigned char *)d_out + narrow_k_offset(n));
+    if (in_narrow)
+        hipLaunchKernelGGL(k_scatter_wcn<true>, dim3(nunits), dim3(WN_THREADS), wn_lds_bytes(bits), st, (const Tup *)nullptr,
+                           (const u64 *)d_in, (const u32 *)((const unsigned char *)d_in + narrow_k_offset(n)), oP, oK,
+                           (const u64 *)nullptr, (const u32 *)nullptr, 0u, (u64)0, shift, bits, d_unit_base, d_rng, nunits,
+                           d_overflow);
+    else
+        hipLaunchKernelGGL(k_scatter_wcn<false>, dim3(nunits), dim3(WN_THREADS), wn_lds_bytes(bits), st, (const Tup *)d_in,
+                           (const u64 *)nullptr, (const u32 *)nullptr, oP, oK, (const u64 *)nullptr, (const u32 *)nullptr, 0u,
+                           (u64)0, shift, bits, d_unit_base, d_rng, nunits, d_overflow);
+}
+
 void launch_diff_hist(hipStream_t st, const u64 *d_start, u64 nbins, u64 *d_hist)
 {
     hipLaunchKernelGGL(k_diff_hist, dim3((unsigned)((nbins + 255) / 256)), dim3(256), 0, st, d_start, nbins, d_hist);
@@ -1830,10 +2101,23 @@ void launch_make_tasks(hipStream_t st, const u64 *d_startR, const u64 *d_startS,
 
 void launch_join(hipStream_t st, const void *d_R, const u64 *d_startR, const void *d_S, const u64 *d_startS,
                  const JoinTask *d_tasks, const u32 *d_ntasks, u32 grid, int radix_bits,
-                 void *d_out, u64 out_capacity, u64 *d_out_count, int kind)
+                 void *d_out, u64 out_capacity, u64 *d_out_count, int kind, const u32 *d_RK, const u32 *d_SK)
 {
     if (grid == 0) return;
     allow_big_lds();
+    const RelView<false> vR{(const Tup *)d_R}, vS{(const Tup *)d_S};
+    if (d_RK != nullptr) {                                                   // narrow partitions (k_scatter_wcn): d_R, d_S are payload arrays
+        const RelView<true> nR{(const u64 *)d_R, d_RK}, nS{(const u64 *)d_S, d_SK};
+        if (kind == JK_CT_HALF)
+            hipLaunchKernelGGL((k_join_ct<CTH_THREADS, CTH_CHUNK, CTH_BUCKET_BITS, CT_EPT, false, true>), dim3(grid), dim3(CTH_THREADS),
+                               ct_lds_bytes(CTH_THREADS, CTH_CHUNK, CTH_BUCKET_BITS), st, nR, nS, d_tasks, d_ntasks, radix_bits,
+                               (Pair *)d_out, out_capacity, d_out_count, (u64 *)nullptr, 0u);
+        else                                                                 // JK_CT (the host never asks for another kind here)
+            hipLaunchKernelGGL((k_join_ct<CT_THREADS, CT_CHUNK, CT_BUCKET_BITS, CT_EPT, false, true>), dim3(grid), dim3(CT_THREADS),
+                               ct_lds_bytes(), st, nR, nS, d_tasks, d_ntasks, radix_bits, (Pair *)d_out, out_capacity,
+                               d_out_count, (u64 *)nullptr, 0u);
+        return;
+    }
     if (kind == JK_BKT) {
         hipLaunchKernelGGL((k_join_bkt<BJ_THREADS, BJ_CHUNK, BJ_BUCKET_BITS, BJ_EPT, false>), dim3(grid), dim3(BJ_THREADS),
                            bj_lds_bytes(BJ_THREADS, BJ_CHUNK, BJ_BUCKET_BITS), st, (const Tup *)d_R, (const Tup *)d_S,
@@ -1847,8 +2131,8 @@ void launch_join(hipStream_t st, const void *d_R, const u64 *d_startR, const voi
         return;
     }
     if (kind == JK_CT_HALF) {
-        hipLaunchKernelGGL((k_join_ct<CTH_THREADS, CTH_CHUNK, CTH_BUCKET_BITS, CT_EPT, false>), dim3(grid), dim3(CTH_THREADS),
-                           ct_lds_bytes(CTH_THREADS, CTH_CHUNK, CTH_BUCKET_BITS), st, (const Tup *)d_R, (const Tup *)d_S, d_tasks,
+        hipLaunchKernelGGL((k_join_ct<CTH_THREADS, CTH_CHUNK, CTH_BUCKET_BITS, CT_EPT, false, false>), dim3(grid), dim3(CTH_THREADS),
+                           ct_lds_bytes(CTH_THREADS, CTH_CHUNK, CTH_BUCKET_BITS), st, vR, vS, d_tasks,
                            d_ntasks, radix_bits, (Pair *)d_out, out_capacity, d_out_count, (u64 *)nullptr, 0u);
         return;
     }
@@ -1858,8 +2142,8 @@ void launch_join(hipStream_t st, const void *d_R, const u64 *d_startR, const voi
         u64 *d_st = nullptr;
         if (hipMalloc(&d_st, (size_t)nw * CT_NSTAMP * 8) != hipSuccess) return;
         (void)hipMemsetAsync(d_st, 0, (size_t)nw * CT_NSTAMP * 8, st);
-        hipLaunchKernelGGL((k_join_ct<CT_THREADS, CT_CHUNK, CT_BUCKET_BITS, CT_EPT, true>), dim3(grid), dim3(CT_THREADS),
-                           ct_lds_bytes(), st, (const Tup *)d_R, (const Tup *)d_S, d_tasks, d_ntasks, radix_bits,
+        hipLaunchKernelGGL((k_join_ct<CT_THREADS, CT_CHUNK, CT_BUCKET_BITS, CT_EPT, true, false>), dim3(grid), dim3(CT_THREADS),
+                           ct_lds_bytes(), st, vR, vS, d_tasks, d_ntasks, radix_bits,
                            (Pair *)d_out, out_capacity, d_out_count, d_st, nw);
         std::vector<u64> h((size_t)nw * CT_NSTAMP);
         (void)hipMemcpyAsync(h.data(), d_st, h.size() * 8, hipMemcpyDeviceToHost, st);
@@ -1883,8 +2167,8 @@ void launch_join(hipStream_t st, const void *d_R, const u64 *d_startR, const voi
         }
         return;
     }
-    hipLaunchKernelGGL((k_join_ct<CT_THREADS, CT_CHUNK, CT_BUCKET_BITS, CT_EPT, false>), dim3(grid), dim3(CT_THREADS),
-                       ct_lds_bytes(), st, (const Tup *)d_R, (const Tup *)d_S, d_tasks, d_ntasks, radix_bits,
+    hipLaunchKernelGGL((k_join_ct<CT_THREADS, CT_CHUNK, CT_BUCKET_BITS, CT_EPT, false, false>), dim3(grid), dim3(CT_THREADS),
+                       ct_lds_bytes(), st, vR, vS, d_tasks, d_ntasks, radix_bits,
                        (Pair *)d_out, out_capacity, d_out_count, (u64 *)nullptr, 0u);
 }
 

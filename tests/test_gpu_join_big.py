@@ -6,7 +6,10 @@ inputs beyond 2^30 tuples:
 Reference semantics: JoinJob::run + Result::join_buckets (JobScheduler.cpp:186-192, Result.cpp:43-76): every
 (rowR,rowS) with equal payloads, build side = smaller bucket.  Checked against the CPU oracle (sorted pair sets) and, at
 10^9 tuples, by count + checksum against the closed form.  rhj_set_option("join.big_tables", 1) makes the engine use
-these kernels whatever the partition sizes, so that small, oracle-sized inputs reach them."""
+these kernels whatever the partition sizes, so that small, oracle-sized inputs reach them.
+The compact-table kernel also reads the narrow intermediate format ({payload 8 B, rowID 4 B}, k_scatter_wcn) that a join
+with a fused two-pass plan uses while rowIDs fit 32 bits: "partition.narrow" 0 / 1 / 2 = 16-byte tuples throughout /
+narrow partitions / narrow between the passes too.  Every case below runs in each format."""
 import numpy as np
 import pytest
 
@@ -18,13 +21,24 @@ pytestmark = pytest.mark.gpu
 BKT_BIG, CT, CT_HALF = 1, 2, 3
 
 
-@pytest.fixture(scope="module", params=[BKT_BIG, CT, CT_HALF], ids=["bkt_big", "compact_table", "compact_table_half"])
+@pytest.fixture(scope="module", params=[(BKT_BIG, 0), (CT, 0), (CT_HALF, 0), (CT, 1), (CT, 2), (CT_HALF, 2)],
+                ids=["bkt_big", "compact_table", "compact_table_half", "compact_table_narrow1", "compact_table_narrow2",
+                     "compact_table_half_narrow2"])
 def big(request):
     e = Engine(0)
     e.set_option("join.big_tables", 1)
-    e.set_option("join.big_kernel", request.param)
+    e.set_option("join.big_kernel", request.param[0])
+    e.narrow = request.param[1]
+    e.set_option("partition.narrow", e.narrow)
     yield e
     e.close()
+
+
+def used_format(engine, plan, wide_rowids=False):
+    """the format the last join ran in: the requested narrow level under a fused 8+8 plan, else 16-byte tuples"""
+    exp = engine.narrow if (plan.passes, plan.bits1, plan.bits2) == (2, 8, 8) and not wide_rowids else 0
+    assert engine.info("last.narrow") == exp
+    engine.set_option("partition.narrow", engine.narrow)        # re-arm after a fallback
 
 
 def rel(rng, n, values, key0=0):
@@ -42,11 +56,12 @@ def few_partitions(values, nlow):
     return (values << np.uint64(16)) | lows[(values % np.uint64(nlow)).astype(np.int64)]
 
 
-def check(engine, oracle, R, S, plan):
+def check(engine, oracle, R, S, plan, wide_rowids=False):
     got = engine.join(R, S, opts=plan)
     exp = oracle.join(R, S)
     assert len(got) == len(exp)
     assert np.array_equal(sorted_pairs(got), sorted_pairs(exp))
+    used_format(engine, plan, wide_rowids)
 
 
 @pytest.mark.parametrize("nR,nS,nlow", [(60_000, 200_000, 3),        # 20 K build / 66 K probe per partition: 2 chunks, 5 tasks
@@ -59,7 +74,7 @@ def test_pkfk_16_bit_plan(big, oracle, nR, nS, nlow):
     rng = np.random.default_rng(nR + nS)
     rv = rng.permutation(1 << 22)[:nR].astype(np.uint64)
     R = rel(rng, nR, few_partitions(rv, nlow))
-    S = rel(rng, nS, R["payload"][rng.integers(0, nR, nS)], key0=1 << 40)
+    S = rel(rng, nS, R["payload"][rng.integers(0, nR, nS)], key0=1 << 31)
     S["payload"][::97] ^= np.uint64(1 << 40)                        # some probe tuples match nothing
     check(big, oracle, R, S, Opts(2, 8, 8))
 
@@ -74,7 +89,7 @@ def test_duplicates_on_both_sides(big, oracle):
     """several matches per probe tuple: the generic (wavefront, slot) loop; output far larger than the inputs"""
     rng = np.random.default_rng(5)
     R = rel(rng, 60_000, few_partitions(rng.integers(0, 9_000, 60_000).astype(np.uint64), 2))
-    S = rel(rng, 50_000, few_partitions(rng.integers(0, 9_000, 50_000).astype(np.uint64), 2), key0=1 << 40)
+    S = rel(rng, 50_000, few_partitions(rng.integers(0, 9_000, 50_000).astype(np.uint64), 2), key0=1 << 31)
     check(big, oracle, R, S, Opts(2, 8, 8))
 
 
@@ -90,9 +105,12 @@ def test_long_buckets_cooperative_scan(big, oracle):
     pv = (rng.permutation(1 << 20)[:90_000].astype(np.uint64) + np.uint64(1000)) << np.uint64(16)
     pv[::9001] = 17 << 16                  # ten probe tuples hit the first hot value ...
     pv[5::30_011] = 18 << 16               # ... three the second
-    P = rel(rng, 90_000, pv, key0=1 << 33)
+    P = rel(rng, 90_000, pv, key0=(1 << 32) - 90_000)                         # rowIDs up to 2^32 - 1: still narrow
     check(big, oracle, B, P, Opts(2, 8, 8))   # B is the smaller side: build
     check(big, oracle, P, B, Opts(2, 8, 8))   # roles swapped: pairs are (rowR,rowS) either way
+    P["key"][77_777] = 1 << 32                                                # one rowID beyond: detected on the device,
+    check(big, oracle, B, P, Opts(2, 8, 8), wide_rowids=True)                 # the join repeats itself with 16-byte tuples
+    check(big, oracle, P, B, Opts(2, 8, 8), wide_rowids=True)
 
 
 def test_all_equal_keys(big):
@@ -101,6 +119,7 @@ def test_all_equal_keys(big):
     big.generate(GEN_CONST, dR, n, 0, 99 << 16)
     big.generate(GEN_CONST, dS, m, 0, 99 << 16)
     assert big.join_dev(dR, n, dS, m, opts=Opts(2, 8, 8)) == n * m
+    used_format(big, Opts(2, 8, 8))
     dO = big.alloc(16 * 500_000)
     assert big.join_dev(dR, n, dS, m, dO, 500_000, opts=Opts(2, 8, 8), allow_overflow=True) == n * m
     part = dO.to_numpy(PAIR, 500_000)
@@ -115,7 +134,9 @@ def test_full_width_rowids(big, oracle):
     R["key"] = rng.integers(0, 1 << 63, n, dtype=np.uint64) * np.uint64(2) + np.uint64(1)
     S = rel(rng, 80_000, R["payload"][rng.integers(0, n, 80_000)])
     S["key"] = rng.integers(0, 1 << 63, 80_000, dtype=np.uint64) * np.uint64(2)
-    check(big, oracle, R, S, Opts(2, 8, 8))
+    check(big, oracle, R, S, Opts(2, 8, 8), wide_rowids=True)
+    S["key"] = np.arange(80_000, dtype=np.uint64)                            # only R's rowIDs are wide
+    check(big, oracle, R, S, Opts(2, 8, 8), wide_rowids=True)
 
 
 def test_under_partitioned_plans_use_the_chunked_kernel(big, oracle):
@@ -135,6 +156,7 @@ def test_skewed_probe_side(big):
     for plan in (Opts(2, 8, 8), Opts(1, 3)):
         assert big.join_dev(dR, nR, dS, nS, dO, nS, opts=plan) == exp_n == nS
         assert big.pairs_checksum(dO, nS) == exp_c
+        used_format(big, plan)
 
 
 def test_bucket_join_stage_big_partitions(big, oracle):
@@ -155,8 +177,10 @@ def test_bucket_join_stage_big_partitions(big, oracle):
     assert np.array_equal(sorted_pairs(dO.to_numpy(PAIR, n)), sorted_pairs(exp))
 
 
-@pytest.mark.parametrize("kind,plan", [(GEN_S_UNIFORM, Opts(2, 8, 8)), (GEN_S_ZIPF, Opts(2, 8, 8)), (GEN_S_ZIPF, Opts())])
-def test_one_billion_count_and_checksum(engine, kind, plan):
+@pytest.mark.parametrize("kind,plan,narrow", [(GEN_S_UNIFORM, Opts(2, 8, 8), -1), (GEN_S_ZIPF, Opts(2, 8, 8), -1),
+                                              (GEN_S_ZIPF, Opts(), -1), (GEN_S_UNIFORM, Opts(2, 8, 8), 0),
+                                              (GEN_S_UNIFORM, Opts(2, 8, 8), 1)])
+def test_one_billion_count_and_checksum(engine, kind, plan, narrow):
     """BASELINE configs 3 and 4 at full size through rhj_join_dev with the engine's own kernel choice: 10^9 x 10^9,
     exact count and order-insensitive checksum of the pair set against the closed form (itself pinned to the oracle
     at 2-3 M tuples)"""
@@ -168,8 +192,13 @@ def test_one_billion_count_and_checksum(engine, kind, plan):
     engine.generate(GEN_R, dR, n, 0, n)
     engine.generate(kind, dS, n, 0, n, seed=42, theta_milli=900)
     exp_n, exp_c = engine.expected_pkfk(dS, n)
-    assert engine.join_dev(dR, n, dS, n, dO, n, opts=plan) == exp_n == n
-    assert engine.pairs_checksum(dO, n) == exp_c
+    engine.set_option("partition.narrow", narrow)
+    try:
+        assert engine.join_dev(dR, n, dS, n, dO, n, opts=plan) == exp_n == n
+        assert engine.pairs_checksum(dO, n) == exp_c
+        assert engine.info("last.narrow") == (2 if narrow < 0 else narrow)      # rowIDs < 2^32: the default is narrow
+    finally:
+        engine.set_option("partition.narrow", -1)
     for b in (dR, dS, dO):
         b.free()
     engine.release_workspace()

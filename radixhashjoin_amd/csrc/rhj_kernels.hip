@@ -654,13 +654,16 @@ dev_scatter_wc(const Tup *__restrict__ in, Tup *__restrict__ out, const u64 *__r
     }
     __syncthreads();
 
+    // Loads are unconditional (slots past the end of a short tile re-read its last tuple; process() ignores them): with a
+    // branch per load the compiler cannot count the loads in flight and waits for vmcnt(0) -- i.e. for the tile it has
+    // just prefetched -- before it touches the current one.
     auto load_tile = [&](Tup (&t)[WC_TPT], u64 tb) {
-        const u32 ntile = (end - tb < (u64)TILE) ? (u32)(end - tb) : (u32)TILE;
+        const u32 last = ((end - tb < (u64)TILE) ? (u32)(end - tb) : (u32)TILE) - 1u;      // tb < end
         const Tup *__restrict__ tp = in + tb;
 #pragma unroll
         for (int k = 0; k < WC_TPT; k++) {
             const u32 i = k * THREADS + tid;
-            if (i < ntile) t[k] = tp[i];
+            t[k] = tp[i < last ? i : last];
         }
     };
     // FULL: the tile has TILE tuples (every tile of a unit but its last): no per-tuple range checks
@@ -753,13 +756,15 @@ dev_scatter_wc(const Tup *__restrict__ in, Tup *__restrict__ out, const u64 *__r
     u64 cur = beg;
     if (cur < end) load_tile(ta, cur);
     while (cur < end) {
+        // the prefetch is issued on every path (past the unit's end: the current tile again, unused), so that the wait for
+        // the current tile is "all but the 4 loads just issued" instead of vmcnt(0)
         u64 nxt = cur + TILE;
-        if (nxt < end) load_tile(tb_, nxt);
+        load_tile(tb_, nxt < end ? nxt : cur);
         if (nxt <= end) process(ta, cur, std::true_type{}); else process(ta, cur, std::false_type{});
         cur = nxt;
         if (cur >= end) break;
         nxt = cur + TILE;
-        if (nxt < end) load_tile(ta, nxt);
+        load_tile(ta, nxt < end ? nxt : cur);
         if (nxt <= end) process(tb_, cur, std::true_type{}); else process(tb_, cur, std::false_type{});
         cur = nxt;
     }
@@ -855,14 +860,12 @@ k_scatter_wcn(const Tup *__restrict__ in, const u64 *__restrict__ inP, const u32
 
     u32 ovf = 0;                                                             // any rowID >= 2^32 seen (16-byte input only)
     auto load_tile = [&](u64 (&pay)[TPT], KeyT (&key)[TPT], u64 tb) {
-        const u32 ntile = (end - tb < (u64)TILE) ? (u32)(end - tb) : (u32)TILE;
+        const u32 last = ((end - tb < (u64)TILE) ? (u32)(end - tb) : (u32)TILE) - 1u;      // tb < end
 #pragma unroll
-        for (int k = 0; k < TPT; k++) {
-            const u32 i = k * THREADS + tid;
-            if (i < ntile) {
-                if constexpr (IN_NARROW) { pay[k] = inP[tb + i]; key[k] = inK[tb + i]; }
-                else { const Tup v = in[tb + i]; pay[k] = v.payload; key[k] = v.key; }
-            }
+        for (int k = 0; k < TPT; k++) {                                      // unconditional loads (see dev_scatter_wc)
+            const u32 i0 = k * THREADS + tid, i = i0 < last ? i0 : last;
+            if constexpr (IN_NARROW) { pay[k] = inP[tb + i]; key[k] = inK[tb + i]; }
+            else { const Tup v = in[tb + i]; pay[k] = v.payload; key[k] = v.key; }
         }
     };
     auto process = [&](u64 (&pay)[TPT], KeyT (&key)[TPT], u64 tb, auto full_tag) {
@@ -962,13 +965,13 @@ k_scatter_wcn(const Tup *__restrict__ in, const u64 *__restrict__ inP, const u32
     u64 cur = beg;
     if (cur < end) load_tile(pa, ka, cur);
     while (cur < end) {
-        u64 nxt = cur + TILE;
-        if (nxt < end) load_tile(pb, kb, nxt);
+        u64 nxt = cur + TILE;                                                // (prefetch on every path: see dev_scatter_wc)
+        load_tile(pb, kb, nxt < end ? nxt : cur);
         if (nxt <= end) process(pa, ka, cur, std::true_type{}); else process(pa, ka, cur, std::false_type{});
         cur = nxt;
         if (cur >= end) break;
         nxt = cur + TILE;
-        if (nxt < end) load_tile(pa, ka, nxt);
+        load_tile(pa, ka, nxt < end ? nxt : cur);
         if (nxt <= end) process(pb, kb, cur, std::true_type{}); else process(pb, kb, cur, std::false_type{});
         cur = nxt;
     }

@@ -190,6 +190,22 @@ __global__ void __launch_bounds__(THREADS) k_stream_lines(const Tup *__restrict_
     }
 }
 
+// AoS16 in -> SoA12 out, linear (the byte mix of a narrow-output pass without any scatter): T threads, tiles of T*TPT
+template <int THREADS, int TPT>
+__global__ void __launch_bounds__(THREADS) k_aos_to_soa(const Tup *__restrict__ in, u64 *__restrict__ outP, u32 *__restrict__ outK, u64 n, u64 L)
+{
+    constexpr u64 TILE = (u64)THREADS * TPT;
+    const u32 u = blockIdx.x, tid = threadIdx.x;
+    const u64 beg = (u64)u * L, end = beg + L < n ? beg + L : n;
+    for (u64 tb = beg; tb < end; tb += TILE) {
+        Tup t[TPT];
+#pragma unroll
+        for (int k = 0; k < TPT; k++) { const u64 i = tb + (u64)k * THREADS + tid; if (i < end) t[k] = in[i]; }
+#pragma unroll
+        for (int k = 0; k < TPT; k++) { const u64 i = tb + (u64)k * THREADS + tid; if (i < end) { outP[i] = t[k].payload; outK[i] = (u32)t[k].key; } }
+    }
+}
+
 template <typename F> static double time_ms(F f, int reps = 5)
 {
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
@@ -284,6 +300,9 @@ int main(int argc, char **argv)
         if (top > n) { fprintf(stderr, "stream test would overrun: %llu > %llu\n", top, n); exit(1); }               \
         rep("AoS16 -> 256 streams/WG, " #NARROW " GR=" #GR, time_ms([&] { hipLaunchKernelGGL((k_stream_lines<512, 4, NARROW, GR>), dim3(G), dim3(512), 76 << 10, 0, in, out, outP, outK, n2, L2); }) * (double)n / (double)n2); \
     }
+        rep("AoS16 -> SoA12 linear T=512 tpt=4 lds=76K", time_ms([&] { hipLaunchKernelGGL((k_aos_to_soa<512, 4>), dim3(G), dim3(512), 76 << 10, 0, in, outP, outK, n, L); }));
+        rep("AoS16 -> SoA12 linear T=1024 tpt=4 lds=150K", time_ms([&] { hipLaunchKernelGGL((k_aos_to_soa<1024, 4>), dim3(G), dim3(1024), 150 << 10, 0, in, outP, outK, n, L); }));
+        rep("AoS16 -> SoA12 linear T=256 tpt=4 lds=0", time_ms([&] { hipLaunchKernelGGL((k_aos_to_soa<256, 4>), dim3(G * 4), dim3(256), 0, 0, in, outP, outK, n, (L + 3) / 4 / 1024 * 1024 + 1024); }));
         RUN_SL(false, 8) RUN_SL(false, 4) RUN_SL(false, 16) RUN_SL(true, 8) RUN_SL(true, 16) RUN_SL(true, 32)
     }
     return 0;

@@ -312,6 +312,11 @@ def main():
         sc_ms = kt["scatter"][0] / max(kt["scatter"][1], 1)
         tuples_per_launch = n                                   # one launch scatters one relation shard once
         achieved = SCATTER_BYTES_PER_TUPLE * tuples_per_launch / (sc_ms * 1e-3) / 1e9 if sc_ms else 0.0
+        # format of the intermediate (rhj_get_info "last.narrow"): inside a join with a fused two-pass plan the scatter
+        # writes {payload 8 B, rowID 4 B} arrays, so the bytes a launch must MOVE are fewer than SURVEY §8d's 32 B/tuple
+        narrow = eng.info("last.narrow")
+        moved_per_tuple = {0: 32.0, 1: (32.0 + 28.0) / 2, 2: (28.0 + 24.0) / 2}[narrow] if args.passes == 2 else 32.0
+        moved = moved_per_tuple * tuples_per_launch / (sc_ms * 1e-3) / 1e9 if sc_ms else 0.0
         part_ms = (kt["hist"][0] + kt["scan"][0] + kt["scatter"][0]) / args.steps
         npass_tuples = 2 * args.passes * n                      # 2 relations x passes
         traffic = None
@@ -330,15 +335,24 @@ def main():
                                    + " radix, inputs and pairs resident in HBM",
                        "tuples_R_global": nglobal, "tuples_S_global": nglobal, "matches_last_step_rank0": cnt,
                        "exchange": "none (single GPU)" if world == 1 else "RCCL all-to-all by balanced owner class ranges"},
-            "roofline": {"bound": "hbm", "kernel": "k_scatter_wc (line-aligned write-combining scatter-partition, one pass over one relation)",
+            "roofline": {"bound": "hbm",
+                         "kernel": ("k_scatter_wcn" if narrow else "k_scatter_wc")
+                                   + " (line-aligned write-combining scatter-partition, one pass over one relation)",
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": traffic, "algorithmic_bytes_per_launch": SCATTER_BYTES_PER_TUPLE * tuples_per_launch,
                          "avg_launch_ms": sc_ms,
+                         "intermediate_format": {0: "16 B tuples", 1: "16 B tuples, then {payload 8 B, rowID 4 B} partitions",
+                                                 2: "{payload 8 B, rowID 4 B} arrays after both passes"}[narrow],
+                         "moved_bytes_per_launch": moved_per_tuple * tuples_per_launch,
+                         "achieved_moved": moved, "frac_moved": moved / HBM_PEAK_GBS,
                          "partition_pass_GBps": (40.0 * npass_tuples / (part_ms * 1e-3) / 1e9) if part_ms else 0.0},
             "kernel_ms_per_step": {k: v[0] / args.steps for k, v in kt.items()},
         }
         line["kernel_GBps"] = {"join (48 B per tuple pair: 16 B per input tuple + 16 B per pair)":
                                48.0 * n / (kt["join"][0] / max(kt["join"][1], 1) * 1e-3) / 1e9 if kt["join"][0] else 0.0,
+                               "join, bytes moved (%d B per input tuple + 16 B per pair)" % (12 if narrow else 16):
+                               ((24.0 if narrow else 32.0) + 16.0) * n / (kt["join"][0] / max(kt["join"][1], 1) * 1e-3) / 1e9
+                               if kt["join"][0] else 0.0,
                                "hist (16 B per tuple)": 16.0 * n / (kt["hist"][0] / max(kt["hist"][1], 1) * 1e-3) / 1e9 if kt["hist"][0] else 0.0}
         if auto is not None:
             line["auto_plan"] = auto

@@ -36,9 +36,9 @@ def short(name):
     return k
 
 
-# FETCH_SIZE correction (MI355X_MICROARCH.md, HBM section): x2 for kernels whose streaming reads are 16 B/lane; the
-# narrow-format kernels read 8 B + 4 B per lane, where the counter is taken as it is
-NARROW_READERS = ("k_scatter_wcn<in_narrow=true>", "narrow>")
+# FETCH_SIZE correction (MI355X_MICROARCH.md, HBM section): x2 for the streaming reads of these kernels.  It holds for
+# the narrow-format kernels (8 B + 4 B per lane) as well: k_scatter_wcn<in_narrow=true> must read its whole 12.0 GB
+# input (far beyond every cache) and the raw counter says 6.01 GB.
 
 
 stats = glob.glob(os.path.join(src, "trace", "*", "*_kernel_stats.csv"))[0]
@@ -68,7 +68,7 @@ for counter, d in (("FETCH_SIZE", "pmc_fetch"), ("WRITE_SIZE", "pmc_write")):
 for k, v in pmc.items():
     f_, w_ = v.get("FETCH_SIZE_KiB_avg"), v.get("WRITE_SIZE_KiB_avg")
     if f_ is not None and w_ is not None:
-        corr = 1 if any(k.endswith(x) or k == x for x in NARROW_READERS) else 2
+        corr = 2
         v["fetch_size_correction"] = corr
         v["hbm_read_bytes_per_launch"] = corr * f_ * 1024   # gfx950 correction for 16 B/lane streams
         v["hbm_write_bytes_per_launch"] = w_ * 1024

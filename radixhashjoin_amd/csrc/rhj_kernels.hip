@@ -1378,8 +1378,10 @@ k_join_bkt(const Tup *__restrict__ R, const Tup *__restrict__ S, const JoinTask 
 //     table (k_join_bkt needs two 8448-tuple chunks and re-reads the probe side per chunk: 64 GB moved for 48 GB
 //     algorithmic, 2.0 TB/s, round 1).
 //   * the probe side streams through a 3-tile register ring; a probe tuple leaves in registers its rowID and its
-//     matches as {first table position of its bucket, bit mask of the matching entries} (512 threads x 256 VGPRs: the
-//     register file, 512 KiB per CU, is the largest memory there is: it holds a whole 16 K-tuple probe task).
+//     matches as {first table position of its bucket, bit mask of the matching entries} (the register file, 512 KiB
+//     per CU, is the largest memory there is: it holds a whole 16 K-tuple probe task).  1024 threads x 128 VGPRs:
+//     four wavefronts per SIMD hide the LDS round trips of the probe phase better than two with twice the slots
+//     each ([measured] 1B x 1B: 10.2 against 12.8 ms narrow, 12.3 against 13.8 ms with 16-byte tuples).
 //     Several matches per probe tuple (duplicates on the build side: every second partition of a PK/FK join builds on
 //     the foreign-key side, JobScheduler.cpp:187) cost nothing extra.
 //   * when every probe is done the keys are dead: the build rowIDs (re-fetched from the partition, see below) are
@@ -1393,19 +1395,19 @@ k_join_bkt(const Tup *__restrict__ R, const Tup *__restrict__ S, const JoinTask 
 // Bucket counts are 16-bit halves of 32-bit LDS words (ds_add_rtn on the word; a half cannot carry: <= 17920 per
 // workgroup), so 8192 buckets cost 16 KiB and the average bucket holds 1.9 entries.
 // ------------------------------------------------------------------------------------------------
-constexpr int CT_THREADS = 512, CT_CHUNK = 17920, CT_BUCKET_BITS = 13, CT_EPT = 32, CT_PT = 4, CT_DEPTH = 3;
+constexpr int CT_THREADS = 1024, CT_CHUNK = 17920, CT_BUCKET_BITS = 13, CT_EPT = 16, CT_PT = 4, CT_DEPTH = 3;
 // the same kernel at half size, for partitions of up to 8960 build tuples (3 ... 5.5 * 10^8 tuples under a 16-bit plan):
-// 256 threads, 80 KiB LDS -> TWO workgroups per CU, which overlap each other's memory and LDS phases; the per-thread
-// register picture (35 build slots, 32 probe slots, 256 VGPRs) is unchanged.  The kernel's cost per task does not shrink
+// 512 threads, 80 KiB LDS -> TWO workgroups per CU, which overlap each other's memory and LDS phases; the per-thread
+// register picture (18 build slots, 16 probe slots, 128 VGPRs) is unchanged.  The kernel's cost per task does not shrink
 // with the partition (every slot row is walked), so the full-size geometry is 2-3x too expensive there (measured at
 // 3 * 10^8: 8.9 ms against 5.1 ms for the chunked 16-byte-entry kernel).
-constexpr int CTH_THREADS = 256, CTH_CHUNK = 8960, CTH_BUCKET_BITS = 12;
+constexpr int CTH_THREADS = 512, CTH_CHUNK = 8960, CTH_BUCKET_BITS = 12;
 constexpr u32 CT_NONE = 0xFFFFu;
 constexpr int CT_MIN_RADIX_BITS = 16;       // keys must fit 48 bits
 constexpr u32 CT_MASK_BITS = 16;            // a probe records its matches as a bit mask over a bucket of at most this many entries
 
 // 32-bit Fibonacci hash of the folded key: one quarter-rate multiply instead of the four of a 64-bit product (the probe
-// phase is issue-bound at two wavefronts per SIMD)
+// phase is latency-bound)
 template <int BBITS>
 __device__ __forceinline__ u32 ct_bucket(u64 key)
 {
@@ -1440,7 +1442,7 @@ template <> struct RelView<true> {
 };
 
 template <int THREADS, int CHUNK, int BBITS, int EPT, bool STAMPS, bool NARROW>
-__global__ void __launch_bounds__(THREADS, 2)       // two wavefronts per SIMD: 256 registers (VGPR + AGPR) per lane
+__global__ void __launch_bounds__(THREADS, THREADS * (CHUNK <= 8960 ? 2 : 1) / 256)   // wavefronts per SIMD: 2 (256 registers per lane) or 4 (128)
 k_join_ct(const RelView<NARROW> R, const RelView<NARROW> S, const JoinTask *__restrict__ tasks,
           const u32 *__restrict__ ntasks, int radix_bits, Pair *__restrict__ out, u64 out_capacity,
           u64 *__restrict__ out_count, u64 *__restrict__ stamps, u32 nstamp_wgs)
@@ -1456,7 +1458,7 @@ k_join_ct(const RelView<NARROW> R, const RelView<NARROW> S, const JoinTask *__re
     constexpr int BPT = (CHUNK + THREADS - 1) / THREADS;            // build tuples per thread
     constexpr int BB = BPT;                                         // build loads in flight per lane: the whole build side
     constexpr int WPT = NB / 2 / THREADS;                           // packed counter words per thread in the scan
-    constexpr int PT = CT_PT, NT = EPT / PT, DEPTH = CT_DEPTH;      // probe tile: PT slots; ring of DEPTH tiles (5 tiles measured slower: 13.2 against 12.75 ms)
+    constexpr int PT = CT_PT, NT = EPT / PT, DEPTH = NARROW ? CT_DEPTH : 1;      // probe tile: PT slots; ring of DEPTH tiles ([measured] narrow: 2, 3, 4 tiles alike, 10.1-10.2 ms; 16-byte tuples: 1 tile 11.8 ms, 2 or 3 tiles 12.4 -- they spill)
     static_assert(EPT % PT == 0 && EPT <= 32 && NB % (2 * THREADS) == 0 && CHUNK < (int)CT_NONE && BPT % BB == 0 && NW <= 64,
                   "geometry");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -1489,7 +1491,7 @@ k_join_ct(const RelView<NARROW> R, const RelView<NARROW> S, const JoinTask *__re
     const int tid0 = tid, nv0 = nv;
     for (u32 cb = 0; cb < nb; cb += CHUNK) {
         const u32 nc = (nb - cb < (u32)CHUNK) ? nb - cb : (u32)CHUNK;
-        // Addresses and range predicates of the 35 build and 32 probe slots depend only on the thread index: left
+        // Addresses and range predicates of the 18 build and 16 probe slots depend only on the thread index: left
         // alone they are hoisted out of this loop into > 100 live registers.  An opaque copy of the thread index per
         // iteration keeps those one-instruction recomputations next to their uses.
         int tid = tid0, nv = nv0;

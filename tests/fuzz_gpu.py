@@ -3,7 +3,9 @@
 Random sizes (incl. tile/unit/table boundaries), value domains, duplicate structure, skew, radix plans and
 probe splits; compares (count, checksum) and, for small outputs, the sorted pair sets.  python tests/fuzz_gpu.py [seconds] [seed]
 RHJ_FUZZ_BIG=1|2|3 forces the oversized-partition kernels (1: chunked 16-byte entries, 2 / 3: compact table at full / half
-size where the plan allows)."""
+size where the plan allows); with RHJ_FUZZ_NARROW=1 half of the cases run the fused 8+8 plan, the one that stores its
+partitions in the narrow {payload, rowID} format (rowIDs start at 10^7 on S; every 16th case has one rowID >= 2^32, which must
+send the join back to 16-byte tuples)."""
 import os, sys, time
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -48,7 +50,7 @@ def rel(n, dom, skew, key0):
     return t
 
 
-t0, cases, maxout = time.time(), 0, 0
+t0, cases, maxout, narrow_runs, fallbacks = time.time(), 0, 0, 0, 0
 while time.time() - t0 < budget:
     nR, nS = size(), size()
     dom = int(rng.choice([1, 2, 5, 100, 4096, 70_000, 1 << 22, 1 << 40]))
@@ -64,7 +66,17 @@ while time.time() - t0 < budget:
     exp_n, exp_c = o.join_count_checksum(R, S)
     assert exp_n == est
     r = rng.random()
-    if r < 0.4:
+    wide = False
+    if os.environ.get("RHJ_FUZZ_NARROW") and rng.random() < 0.5:
+        r = 2.0
+        e.set_option("partition.narrow", int(rng.integers(1, 3)))
+        if cases % 16 == 7:
+            (R if rng.random() < 0.5 else S)["key"][int(rng.integers(0, min(nR, nS)))] = np.uint64(1 << 32) + np.uint64(cases)
+            wide = True
+            exp_n, exp_c = o.join_count_checksum(R, S)
+    if r == 2.0:
+        opts = rhj.Opts(2, 8, 8, int(rng.choice([0, 4096, 32768])))
+    elif r < 0.4:
         opts = None
     elif r < 0.55:
         opts = rhj.Opts(0, 0, 0, int(rng.choice([0, 4096, 8192])))
@@ -75,7 +87,9 @@ while time.time() - t0 < budget:
     else:                                                                    # >= 16 bits: what the compact-table kernel serves
         opts = rhj.Opts(2, int(rng.integers(8, 11)), int(rng.integers(8, 11)), int(rng.choice([0, 4096, 32768])))
     got = e.join(R, S, opts=opts)
-    ok = (len(got), o.pairs_checksum(got)) == (exp_n, exp_c)
+    narrow_runs += 1 if e.info("last.narrow") else 0
+    fallbacks += 1 if wide else 0
+    ok = (len(got), o.pairs_checksum(got)) == (exp_n, exp_c) and not (wide and e.info("last.narrow"))
     if ok and exp_n <= 300_000:
         ok = np.array_equal(sorted_pairs(got), sorted_pairs(o.join(R, S)))
     if not ok:
@@ -83,4 +97,5 @@ while time.time() - t0 < budget:
         sys.exit(1)
     cases += 1
     maxout = max(maxout, exp_n)
-print(f"fuzz ok: {cases} random joins in {time.time() - t0:.0f} s, largest output {maxout} pairs, seed {seed}")
+print(f"fuzz ok: {cases} random joins in {time.time() - t0:.0f} s, largest output {maxout} pairs, seed {seed}; "
+      f"{narrow_runs} ran in the narrow format, {fallbacks} had a rowID >= 2^32")

@@ -467,7 +467,11 @@ int narrow_level(const rhj_ctx *ctx, u64 nR, u64 nS, const rhj_opts &plan)
     if (lo < NARROW_MIN_TUPLES || hi >= ((u64)1 << 32)) return 0;
     const int tb = plan.bits1 + plan.bits2;
     const int kind = choose_join_kind(ctx, nR, nS, (u64)1 << tb, tb);
-    if (kind != JK_CT && kind != JK_CT_HALF) return 0;
+    if (kind != JK_CT && kind != JK_CT_HALF && kind != JK_BKT) return 0;
+    // the narrow scatter has one 1024-thread workgroup per CU and 32-tuple lines to start and finish per digit and unit:
+    // below a few million tuples its fixed costs outweigh the bytes it saves (forced levels, used by the tests, skip this)
+    static const u64 min_auto = getenv("RHJ_NARROW_MIN") ? strtoull(getenv("RHJ_NARROW_MIN"), nullptr, 10) : NARROW_AUTO_MIN_TUPLES;
+    if (ctx->opt_narrow < 0 && hi < min_auto) return 0;
     return want >= 2 ? 2 : 1;
 }
 
@@ -540,7 +544,8 @@ int join_phase_on(rhj_ctx *ctx, const void *d_Rp, const u64 *d_psR, u64 nR, cons
     // a task addresses its build range with 32 bits; k_make_tasks reports any partition whose build side is larger
     // (counters[5], checked below) whatever the plan
     const int kind = choose_join_kind(ctx, nR, nS, nparts, radix_bits);
-    if (narrow && kind != JK_CT && kind != JK_CT_HALF) return fail(ctx, RHJ_E_INVALID, "narrow partitions need the compact-table join");
+    if (narrow && kind != JK_CT && kind != JK_CT_HALF && kind != JK_BKT)
+        return fail(ctx, RHJ_E_INVALID, "no bucket-join kernel for narrow partitions under this plan");
     if (join_probe_split(kind) && probe_split > join_probe_split(kind)) probe_split = join_probe_split(kind);
     const u64 max_tasks64 = nparts + (nR + nS) / probe_split + 1;
     if (max_tasks64 > 0x7fffffffull) return fail(ctx, RHJ_E_INVALID, "too many join tasks");

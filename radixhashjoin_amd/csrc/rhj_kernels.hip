@@ -1148,9 +1148,32 @@ __device__ __forceinline__ u32 bj_bucket(u64 v, int radix_bits)
 // result that outgrows the landing zone needs no second run: the rest is fetched from `out`.
 struct DirectJoin { u32 nb, np, build_is_S, split; u64 *host_count; u32 *done; Pair *host_out; u64 host_cap; };
 
-template <int THREADS, int CHUNK, int BBITS, int EPT, bool DIRECT>
+// A partitioned relation as the join kernels read it: 16-byte tuples, or the narrow {payload 8 B, rowID 4 B} arrays that
+// k_scatter_wcn writes (NARROW: the build phase then reads 8 B per tuple and the rowID re-fetch 4 B instead of 16 + 16)
+template <bool NARROW> struct RelView;
+template <> struct RelView<false> {
+    typedef u64 Rid;
+    struct Both { u64 key, payload; };
+    const Tup *__restrict__ t;
+    __device__ __forceinline__ RelView at(u64 off) const { return RelView{t + off}; }
+    __device__ __forceinline__ u64 payload(u32 i) const { return t[i].payload; }
+    __device__ __forceinline__ Rid rowid(u32 i) const { return t[i].key; }
+    __device__ __forceinline__ Both both(u32 i) const { const Tup v = t[i]; return Both{v.key, v.payload}; }
+};
+template <> struct RelView<true> {
+    typedef u32 Rid;
+    struct Both { u32 key; u64 payload; };
+    const u64 *__restrict__ p;
+    const u32 *__restrict__ k;
+    __device__ __forceinline__ RelView at(u64 off) const { return RelView{p + off, k + off}; }
+    __device__ __forceinline__ u64 payload(u32 i) const { return p[i]; }
+    __device__ __forceinline__ Rid rowid(u32 i) const { return k[i]; }
+    __device__ __forceinline__ Both both(u32 i) const { return Both{k[i], p[i]}; }
+};
+
+template <int THREADS, int CHUNK, int BBITS, int EPT, bool DIRECT, bool NARROW = false>
 __global__ void __launch_bounds__(THREADS, 4)
-k_join_bkt(const Tup *__restrict__ R, const Tup *__restrict__ S, const JoinTask *__restrict__ tasks,
+k_join_bkt(const RelView<NARROW> R, const RelView<NARROW> S, const JoinTask *__restrict__ tasks,
            const u32 *__restrict__ ntasks, int radix_bits, Pair *__restrict__ out, u64 out_capacity,
            u64 *__restrict__ out_count, DirectJoin dj)
 {
@@ -1180,29 +1203,30 @@ k_join_bkt(const Tup *__restrict__ R, const Tup *__restrict__ S, const JoinTask 
         task = tasks[blockIdx.x];
     }
     const bool build_is_S = task.build_is_S != 0;
-    const Tup *__restrict__ B = (build_is_S ? S : R) + task.bbeg;
-    const Tup *__restrict__ P = (build_is_S ? R : S) + task.pbeg;
+    typedef typename RelView<NARROW>::Both Both;
+    const RelView<NARROW> B = (build_is_S ? S : R).at(task.bbeg);
+    const RelView<NARROW> P = (build_is_S ? R : S).at(task.pbeg);
     const u32 nb = task.blen, np = task.plen;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
 
     // first probe tile: in flight while the table is built
-    Tup p[EPT];
+    Both p[EPT];
 #pragma unroll
     for (int k = 0; k < EPT; k++) {
         const u32 i = (u32)k * THREADS + tid;
-        if (i < np) p[k] = P[i];
+        if (i < np) p[k] = P.both(i);
     }
 
     for (u32 cb = 0; cb < nb; cb += CHUNK) {
         const u32 nc = (nb - cb < (u32)CHUNK) ? nb - cb : (u32)CHUNK;
         // ---- build: counting sort of the chunk by hash bucket ---------------------------------
         for (u32 h = tid; h <= NB; h += THREADS) off[h] = 0;
-        Tup bt[BPT];
+        Both bt[BPT];
         u32 br[BPT];
 #pragma unroll
         for (int k = 0; k < BPT; k++) {
             const u32 i = (u32)k * THREADS + tid;
-            if (i < nc) bt[k] = B[cb + i];
+            if (i < nc) bt[k] = B.both(cb + i);
         }
         __syncthreads();
 #pragma unroll
@@ -1240,7 +1264,7 @@ k_join_bkt(const Tup *__restrict__ R, const Tup *__restrict__ S, const JoinTask 
 #pragma unroll
                 for (int k = 0; k < EPT; k++) {
                     const u32 i = tb + (u32)k * THREADS + tid;
-                    if (i < np) p[k] = P[i];
+                    if (i < np) p[k] = P.both(i);
                 }
             }
             u32 cnt[EPT], pre[EPT];
@@ -1329,7 +1353,7 @@ k_join_bkt(const Tup *__restrict__ R, const Tup *__restrict__ S, const JoinTask 
                             const int leader = __ffsll((long long)heavy) - 1;
                             heavy &= heavy - 1;
                             const u64 key = bj_readlane64(p[k].payload, leader);
-                            const u64 pkey = bj_readlane64(p[k].key, leader);
+                            const u64 pkey = bj_readlane64((u64)p[k].key, leader);
                             u64 ob = bj_readlane64(o, leader);
                             const u32 l = __builtin_amdgcn_readlane(lo, leader), hh = __builtin_amdgcn_readlane(hi, leader);
                             for (u32 j = l; j < hh; j += 64) {
@@ -1417,29 +1441,6 @@ __device__ __forceinline__ u32 ct_bucket(u64 key)
 // STAMPS: tuning aid (RHJ_CT_STAMPS=1): thread 0 of the first workgroups records s_memrealtime (100 MHz) at phase
 // boundaries into `stamps` (CT_NSTAMP words per workgroup); never set in production launches.
 constexpr int CT_NSTAMP = 16;
-
-// A partitioned relation as the join kernels read it: 16-byte tuples, or the narrow {payload 8 B, rowID 4 B} arrays that
-// k_scatter_wcn writes (NARROW: the build phase then reads 8 B per tuple and the rowID re-fetch 4 B instead of 16 + 16)
-template <bool NARROW> struct RelView;
-template <> struct RelView<false> {
-    typedef u64 Rid;
-    struct Both { u64 key, payload; };
-    const Tup *__restrict__ t;
-    __device__ __forceinline__ RelView at(u64 off) const { return RelView{t + off}; }
-    __device__ __forceinline__ u64 payload(u32 i) const { return t[i].payload; }
-    __device__ __forceinline__ Rid rowid(u32 i) const { return t[i].key; }
-    __device__ __forceinline__ Both both(u32 i) const { const Tup v = t[i]; return Both{v.key, v.payload}; }
-};
-template <> struct RelView<true> {
-    typedef u32 Rid;
-    struct Both { u32 key; u64 payload; };
-    const u64 *__restrict__ p;
-    const u32 *__restrict__ k;
-    __device__ __forceinline__ RelView at(u64 off) const { return RelView{p + off, k + off}; }
-    __device__ __forceinline__ u64 payload(u32 i) const { return p[i]; }
-    __device__ __forceinline__ Rid rowid(u32 i) const { return k[i]; }
-    __device__ __forceinline__ Both both(u32 i) const { return Both{k[i], p[i]}; }
-};
 
 template <int THREADS, int CHUNK, int BBITS, int EPT, bool STAMPS, bool NARROW>
 __global__ void __launch_bounds__(THREADS, THREADS * (CHUNK <= 8960 ? 2 : 1) / 256)   // wavefronts per SIMD: 2 (256 registers per lane) or 4 (128)
@@ -1894,6 +1895,9 @@ static void allow_big_lds()
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_join_bkt<BJ_THREADS, BJ_CHUNK, BJ_BUCKET_BITS, BJ_EPT, true>),
                               hipFuncAttributeMaxDynamicSharedMemorySize,
                               (int)bj_lds_bytes(BJ_THREADS, BJ_CHUNK, BJ_BUCKET_BITS));
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_join_bkt<BJ_THREADS, BJ_CHUNK, BJ_BUCKET_BITS, BJ_EPT, false, true>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize,
+                              (int)bj_lds_bytes(BJ_THREADS, BJ_CHUNK, BJ_BUCKET_BITS));
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_join_bkt<BJ2_THREADS, BJ2_CHUNK, BJ2_BUCKET_BITS, BJ2_EPT, false>),
                               hipFuncAttributeMaxDynamicSharedMemorySize,
                               (int)bj_lds_bytes(BJ2_THREADS, BJ2_CHUNK, BJ2_BUCKET_BITS));
@@ -2113,7 +2117,11 @@ void launch_join(hipStream_t st, const void *d_R, const u64 *d_startR, const voi
     const RelView<false> vR{(const Tup *)d_R}, vS{(const Tup *)d_S};
     if (d_RK != nullptr) {                                                   // narrow partitions (k_scatter_wcn): d_R, d_S are payload arrays
         const RelView<true> nR{(const u64 *)d_R, d_RK}, nS{(const u64 *)d_S, d_SK};
-        if (kind == JK_CT_HALF)
+        if (kind == JK_BKT)
+            hipLaunchKernelGGL((k_join_bkt<BJ_THREADS, BJ_CHUNK, BJ_BUCKET_BITS, BJ_EPT, false, true>), dim3(grid), dim3(BJ_THREADS),
+                               bj_lds_bytes(BJ_THREADS, BJ_CHUNK, BJ_BUCKET_BITS), st, nR, nS, d_tasks, d_ntasks, radix_bits,
+                               (Pair *)d_out, out_capacity, d_out_count, DirectJoin{});
+        else if (kind == JK_CT_HALF)
             hipLaunchKernelGGL((k_join_ct<CTH_THREADS, CTH_CHUNK, CTH_BUCKET_BITS, CT_EPT, false, true>), dim3(grid), dim3(CTH_THREADS),
                                ct_lds_bytes(CTH_THREADS, CTH_CHUNK, CTH_BUCKET_BITS), st, nR, nS, d_tasks, d_ntasks, radix_bits,
                                (Pair *)d_out, out_capacity, d_out_count, (u64 *)nullptr, 0u);
@@ -2125,13 +2133,13 @@ void launch_join(hipStream_t st, const void *d_R, const u64 *d_startR, const voi
     }
     if (kind == JK_BKT) {
         hipLaunchKernelGGL((k_join_bkt<BJ_THREADS, BJ_CHUNK, BJ_BUCKET_BITS, BJ_EPT, false>), dim3(grid), dim3(BJ_THREADS),
-                           bj_lds_bytes(BJ_THREADS, BJ_CHUNK, BJ_BUCKET_BITS), st, (const Tup *)d_R, (const Tup *)d_S,
+                           bj_lds_bytes(BJ_THREADS, BJ_CHUNK, BJ_BUCKET_BITS), st, vR, vS,
                            d_tasks, d_ntasks, radix_bits, (Pair *)d_out, out_capacity, d_out_count, DirectJoin{});
         return;
     }
     if (kind == JK_BKT_BIG) {
         hipLaunchKernelGGL((k_join_bkt<BJ2_THREADS, BJ2_CHUNK, BJ2_BUCKET_BITS, BJ2_EPT, false>), dim3(grid), dim3(BJ2_THREADS),
-                           bj_lds_bytes(BJ2_THREADS, BJ2_CHUNK, BJ2_BUCKET_BITS), st, (const Tup *)d_R, (const Tup *)d_S,
+                           bj_lds_bytes(BJ2_THREADS, BJ2_CHUNK, BJ2_BUCKET_BITS), st, vR, vS,
                            d_tasks, d_ntasks, radix_bits, (Pair *)d_out, out_capacity, d_out_count, DirectJoin{});
         return;
     }
@@ -2193,8 +2201,9 @@ void launch_join_direct(hipStream_t st, const void *d_R, u64 nR, const void *d_S
     dj.split = (u32)BJ_TILE;
     const u32 grid = (dj.np + dj.split - 1) / dj.split;
     hipLaunchKernelGGL((k_join_bkt<BJ_THREADS, BJ_CHUNK, BJ_BUCKET_BITS, BJ_EPT, true>), dim3(grid), dim3(BJ_THREADS),
-                       bj_lds_bytes(BJ_THREADS, BJ_CHUNK, BJ_BUCKET_BITS), st, (const Tup *)d_R, (const Tup *)d_S,
-                       (const JoinTask *)nullptr, (const u32 *)nullptr, 0, (Pair *)d_out, out_capacity, d_out_count, dj);
+                       bj_lds_bytes(BJ_THREADS, BJ_CHUNK, BJ_BUCKET_BITS), st, RelView<false>{(const Tup *)d_R},
+                       RelView<false>{(const Tup *)d_S}, (const JoinTask *)nullptr, (const u32 *)nullptr, 0, (Pair *)d_out,
+                       out_capacity, d_out_count, dj);
 }
 
 static unsigned stream_grid(u64 n)

@@ -177,6 +177,31 @@ def test_bucket_join_stage_big_partitions(big, oracle):
     assert np.array_equal(sorted_pairs(dO.to_numpy(PAIR, n)), sorted_pairs(exp))
 
 
+@pytest.mark.parametrize("narrow", [1, 2])
+@pytest.mark.parametrize("plan", [Opts(2, 5, 5), Opts(2, 8, 7), Opts(2, 3, 8), Opts(2, 8, 8), Opts(2, 4, 4)])
+def test_narrow_format_with_the_one_table_join(engine, oracle, plan, narrow):
+    """fused two-pass plans whose partitions fit one 16-byte-entry table (k_join_bkt reading the narrow arrays): the
+    automatic choice from 8M tuples on, forced here on oracle-sized inputs; duplicates on both sides, probe tuples without
+    a partner, rowIDs up to 2^32 - 1, and the fall-back on a larger one"""
+    rng = np.random.default_rng(plan.bits1 * 16 + plan.bits2 + narrow)
+    nR, nS = 150_000, 260_000
+    R = rel(rng, nR, rng.integers(0, 100_000, nR).astype(np.uint64) * np.uint64(0x9E3779B97F4A7C15))
+    S = rel(rng, nS, R["payload"][rng.integers(0, nR, nS)], key0=(1 << 32) - nS)
+    S["payload"][::53] ^= np.uint64(1 << 50)
+    engine.set_option("partition.narrow", narrow)
+    try:
+        for wide in (False, True):
+            if wide:
+                R["key"][12_345] = np.uint64(1 << 32)
+            got = engine.join(R, S, opts=plan)
+            exp = oracle.join(R, S)
+            assert len(got) == len(exp) and np.array_equal(sorted_pairs(got), sorted_pairs(exp))
+            assert engine.info("last.narrow") == (0 if wide else narrow) and engine.info("last.join_kernel") == 0
+            engine.set_option("partition.narrow", narrow)
+    finally:
+        engine.set_option("partition.narrow", -1)
+
+
 @pytest.mark.parametrize("kind,plan,narrow", [(GEN_S_UNIFORM, Opts(2, 8, 8), -1), (GEN_S_ZIPF, Opts(2, 8, 8), -1),
                                               (GEN_S_ZIPF, Opts(), -1), (GEN_S_UNIFORM, Opts(2, 8, 8), 0),
                                               (GEN_S_UNIFORM, Opts(2, 8, 8), 1)])

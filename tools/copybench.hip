@@ -164,7 +164,7 @@ __global__ void __launch_bounds__(THREADS) k_scatter_lines(const Tup *__restrict
 
 // AoS16 in -> the scatter's real write pattern: 256 sequential streams per workgroup, each advancing by one chunk of GR
 // tuples at a time.  NARROW: chunk = GR*8 B of payloads + GR*4 B of rowids in two arrays; else GR*16 B in one.
-template <int THREADS, int TPT, bool NARROW, int GR>
+template <int THREADS, int TPT, bool NARROW, int GR, int MODE = 0>
 __global__ void __launch_bounds__(THREADS) k_stream_lines(const Tup *__restrict__ in, Tup *__restrict__ out, u64 *__restrict__ outP,
                                                           u32 *__restrict__ outK, u64 n, u64 L)
 {
@@ -175,8 +175,10 @@ __global__ void __launch_bounds__(THREADS) k_stream_lines(const Tup *__restrict_
     u64 j = 0;
     for (u64 tb = beg; tb < end; tb += TILE, j++) {
         Tup t[TPT];
+        // MODE 1: the READ side is tile-interleaved over the workgroups (tile j of workgroup u = global tile j * G + u)
+        const u64 rb = MODE == 0 ? tb : (j * G + u) * TILE;
 #pragma unroll
-        for (int k = 0; k < TPT; k++) { const u64 i = tb + (u64)k * THREADS + tid; if (i < end) t[k] = in[i]; }
+        for (int k = 0; k < TPT; k++) { const u64 i = rb + (u64)k * THREADS + tid; if (tb + (u64)k * THREADS + tid < end && i < n) t[k] = in[i]; }
 #pragma unroll
         for (int k = 0; k < TPT; k++) {
             const u32 it = k * THREADS + tid;
@@ -303,6 +305,14 @@ int main(int argc, char **argv)
         rep("AoS16 -> SoA12 linear T=512 tpt=4 lds=76K", time_ms([&] { hipLaunchKernelGGL((k_aos_to_soa<512, 4>), dim3(G), dim3(512), 76 << 10, 0, in, outP, outK, n, L); }));
         rep("AoS16 -> SoA12 linear T=1024 tpt=4 lds=150K", time_ms([&] { hipLaunchKernelGGL((k_aos_to_soa<1024, 4>), dim3(G), dim3(1024), 150 << 10, 0, in, outP, outK, n, L); }));
         rep("AoS16 -> SoA12 linear T=256 tpt=4 lds=0", time_ms([&] { hipLaunchKernelGGL((k_aos_to_soa<256, 4>), dim3(G * 4), dim3(256), 0, 0, in, outP, outK, n, (L + 3) / 4 / 1024 * 1024 + 1024); }));
+#define RUN_SLM(T, MODE)                                                                                             \
+    {                                                                                                                \
+        const u64 n2 = n - (64ull << 20), L2 = ((n2 + G - 1) / G + 4095) / 4096 * 4096;                              \
+        const u64 top = 256ull * G * ((L2 / 32 + 255) / 256) * 32;                                                   \
+        if (top > n) { fprintf(stderr, "stream test would overrun\n"); exit(1); }                                    \
+        rep("AoS16 -> 256 streams/WG narrow GR=32, T=" #T " lds=150K, read " #MODE, time_ms([&] { hipLaunchKernelGGL((k_stream_lines<T, 4, true, 32, MODE>), dim3(G), dim3(T), 150 << 10, 0, in, out, outP, outK, n2, L2); }) * (double)n / (double)n2); \
+    }
+        RUN_SLM(1024, 0) RUN_SLM(1024, 1) RUN_SLM(1024, 0) RUN_SLM(1024, 1)
         RUN_SL(false, 8) RUN_SL(false, 4) RUN_SL(false, 16) RUN_SL(true, 8) RUN_SL(true, 16) RUN_SL(true, 32)
     }
     return 0;

@@ -353,7 +353,7 @@ int run_pass_pair(rhj_ctx *ctx, const void *d_R, u64 nR, void *outR, u64 *psR, c
 
 // Two passes with ONE histogram read (k_hist2d_units): used when both passes fit the write-combining scatter
 // and b1 + b2 <= 16.  Pass-2 units = pieces of each pass-1 bucket written by groups of pass-1 units.
-// narrow: 0 = 16-byte tuples throughout; 1 = pass 2 writes the narrow format (for the compact-table join); 2 = pass 1 too
+// narrow: 0 = 16-byte tuples throughout; 1 = pass 2 writes the narrow format (what the join kernel then reads); 2 = pass 1 too
 int partition_relation_fused(rhj_ctx *ctx, const void *d_in, u64 n, int b1, int b2, void *d_out, u64 *d_ps, int narrow = 0)
 {
     // 1024 pass-1 units instead of 2048: every unit flushes a 2^(b1+b2)-bin table, and the scatter does not care
@@ -455,8 +455,9 @@ int choose_join_kind(const rhj_ctx *ctx, u64 nR, u64 nS, u64 nparts, int radix_b
     return half ? JK_CT_HALF : JK_CT;
 }
 
-// The narrow intermediate format applies to the planned large case: fused two-pass plan, compact-table join, rowIDs
-// that can be 32 bits.  Returns the level (0 = not at all).
+// The narrow intermediate format applies to fused two-pass plans (both passes <= 8 bits) whose bucket join is the one-table
+// kernel or the compact-table kernel, for relations of < 2^32 tuples (rowIDs that CAN be 32 bits; whether they are is
+// found out on the device).  Returns the level (0 = not at all).
 int narrow_level(const rhj_ctx *ctx, u64 nR, u64 nS, const rhj_opts &plan)
 {
     static const int env = getenv("RHJ_NARROW") ? atoi(getenv("RHJ_NARROW")) : 2;

@@ -168,6 +168,29 @@ def extras(eng, torch, dev, steps, which="all"):
     sec = (time.perf_counter() - t0) / reps
     res["small_work_94_joins_rhj_join"] = {"total_ms": sec * 1e3, "mean_us_per_join": sec / len(cases) * 1e6,
                                            "tuples_per_s": sum(len(a) + len(b) for a, b in cases) / sec}
+    # the same 94 joins the way the reference issues them: 8 query threads (join.cpp:42-43, MainScheduler.cpp:6-14), each
+    # with its own scheduler = its own rhj_ctx and HIP stream; ctypes releases the GIL inside the C call
+    import threading
+    nthr = 8
+    engines = [rhj.Engine(0) for _ in range(nthr)]
+    for k, e2 in enumerate(engines):
+        for Rt, St in cases[k::nthr]:
+            e2.join_count_only_page(Rt, St)
+    def work(k, reps_):
+        for _ in range(reps_):
+            for Rt, St in cases[k::nthr]:
+                engines[k].join_count_only_page(Rt, St)
+    t0 = time.perf_counter()
+    thr = [threading.Thread(target=work, args=(k, reps)) for k in range(nthr)]
+    for t in thr:
+        t.start()
+    for t in thr:
+        t.join()
+    sec8 = (time.perf_counter() - t0) / reps
+    for e2 in engines:
+        e2.close()
+    res["small_work_94_joins_rhj_join_8_query_threads"] = {"total_ms": sec8 * 1e3, "mean_us_per_join": sec8 / len(cases) * 1e6,
+                                                           "note": "wall time of the 94 calls spread over 8 host threads, one context each"}
     return res
 
 

@@ -1734,7 +1734,8 @@ k_join_ct(const RelView<NARROW> R, const RelView<NARROW> S, const JoinTask *__re
                             Pair pr;
                             if (build_is_S) { pr.r = prid[k]; pr.s = br; }      // orderFlag, Result.cpp:64-68
                             else            { pr.r = br; pr.s = prid[k]; }
-                            out[dst] = pr;
+                            typedef u64 u64x2 __attribute__((ext_vector_type(2)));
+                            __builtin_nontemporal_store(u64x2{pr.r, pr.s}, reinterpret_cast<u64x2 *>(out + dst));
                         }
                     }
                     o += (u64)__popcll(bal);

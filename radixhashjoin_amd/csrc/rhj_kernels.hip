@@ -927,8 +927,8 @@ k_scatter_wcn(const Tup *__restrict__ in, const u64 *__restrict__ inP, const u32
             const u64 x = LB[d];
             if (x != ~0ull && j >= (u32)(x & GM)) {
                 const u64 o = (x & ~GM) + j;
-                outP[o] = sp[TILE + q];
-                outK[o] = sk[TILE + q];
+                __builtin_nontemporal_store(sp[TILE + q], &outP[o]);
+                __builtin_nontemporal_store(sk[TILE + q], &outK[o]);
             }
         }
         const u32 mt = *mtot;
@@ -939,7 +939,7 @@ k_scatter_wcn(const Tup *__restrict__ in, const u64 *__restrict__ inP, const u32
             if (i < mt) {
                 const u64 v = sp[i];
                 const u32 d = (u32)(v >> shift) & mask;
-                if (i < T[d]) { const u64 o = A[d] + i; outP[o] = v; outK[o] = sk[i]; }      // whole lines [a, b)
+                if (i < T[d]) { const u64 o = A[d] + i; __builtin_nontemporal_store(v, &outP[o]); __builtin_nontemporal_store(sk[i], &outK[o]); }      // whole lines [a, b)
                 else keep |= 1u << k;                                                       // tail [b, e): carried on
             }
         }
@@ -982,8 +982,8 @@ k_scatter_wcn(const Tup *__restrict__ in, const u64 *__restrict__ inP, const u32
         const u64 g = gnext[d];
         if (j >= LO[d] && j < (u32)(g & GM)) {
             const u64 o = (g & ~GM) + j;
-            outP[o] = sp[TILE + q];
-            outK[o] = sk[TILE + q];
+            __builtin_nontemporal_store(sp[TILE + q], &outP[o]);
+            __builtin_nontemporal_store(sk[TILE + q], &outK[o]);
         }
     }
     if constexpr (!IN_NARROW) {

@@ -238,6 +238,11 @@ int resolve_plan(u64 nR, u64 nS, const rhj_opts *in, rhj_opts *out)
             if (nb > (u64)BJ_CHUNK && !direct) bits = ilog2_ceil((nb + fit - 1) / fit);
             if (bits == 0) o.passes = 0;
             else if (bits <= 9) { o.passes = 1; o.bits1 = bits; }
+            // Up to two 8448-tuple chunks per partition after ONE 9-bit pass (both relations through the same launches,
+            // ~10 launches in all; the chunked 16-byte-entry kernel joins): a two-pass plan costs ~27 launches, 0.2 ms of
+            // fixed latency that such a join does not have to spare.  [measured] 3M x 3M 0.23 against 0.37 ms, 4M 0.28 / 0.44,
+            // 8M 0.56 / 0.61.
+            else if (nb <= (u64)512 * 2 * join_table_tuples(JK_BKT_BIG) * 15 / 16) { o.passes = 1; o.bits1 = 9; }
             else {
                 // Two passes.  Up to 16 bits both histograms come from ONE read of the input (k_hist2d_units); a 17- or
                 // 18-bit plan re-reads each relation once more just to count (10.7 instead of 5.4 ms per 10^9-tuple join).

@@ -103,7 +103,9 @@ int  rhj_sync(rhj_ctx *ctx);                             /* JobScheduler::barrie
 int  rhj_reserve(rhj_ctx *ctx, uint64_t nR, uint64_t nS, const rhj_opts *opts);
 int  rhj_release_workspace(rhj_ctx *ctx);
 void rhj_default_opts(rhj_opts *opts);
-/* the plan rhj_join* would use for these sizes (host logic only, no device needed; ctx may be NULL) */
+/* the plan rhj_join would use for these sizes (host logic only, no device needed).  rhj_join_dev plans the same
+ * except for build sides of 21 K - 51 K tuples, which it partitions with one pass where rhj_join stays unpartitioned
+ * (one launch matters more when the inputs still have to cross PCIe); rhj_get_timings reports the plan that ran. */
 int  rhj_plan(uint64_t nR, uint64_t nS, const rhj_opts *in, rhj_opts *resolved);
 
 /* ---- the drop-in: replaces the body of Result::multiRadixHashJoin (Result.cpp:90-124) ----

@@ -218,7 +218,8 @@ int ilog2_ceil(u64 x)
 // ---- radix plan (host logic) --------------------------------------------------------------------
 // Reference: one fixed 8-bit pass (Result.cpp:5,91).  Here: the fewest radix bits such that the
 // average build-side partition fills at most 15/16 of one LDS hash table (BJ_CHUNK), in <= 2 passes.
-int resolve_plan(u64 nR, u64 nS, const rhj_opts *in, rhj_opts *out)
+// device_resident: the inputs are in HBM already (rhj_join_dev); else the host-pointer call, whose small path is one launch
+int resolve_plan(u64 nR, u64 nS, const rhj_opts *in, rhj_opts *out, bool device_resident = false)
 {
     rhj_opts o;
     if (in) o = *in; else rhj_default_opts(&o);
@@ -234,7 +235,7 @@ int resolve_plan(u64 nR, u64 nS, const rhj_opts *in, rhj_opts *out)
             const u64 np_ = nR < nS ? nS : nR;
             // small joins stay unpartitioned (one launch, every probe tile re-builds the few table chunks): a partition
             // pass costs ~6 launches per relation, more than such a join itself
-            const bool direct = nb <= DIRECT_MAX_BUILD && np_ <= DIRECT_MAX_PROBE;
+            const bool direct = nb <= (device_resident ? DIRECT_MAX_BUILD_DEV : DIRECT_MAX_BUILD) && np_ <= DIRECT_MAX_PROBE;
             if (nb > (u64)BJ_CHUNK && !direct) bits = ilog2_ceil((nb + fit - 1) / fit);
             if (bits == 0) o.passes = 0;
             else if (bits <= 9) { o.passes = 1; o.bits1 = bits; }
@@ -810,7 +811,7 @@ int rhj_join_dev(rhj_ctx *ctx, const rhj_tuple *d_R, uint64_t nR, const rhj_tupl
     if (nR == 0 || nS == 0) return RHJ_OK;            // nothing to schedule (Result.cpp:101 never fires)
     if (!d_R || !d_S) return fail(ctx, RHJ_E_INVALID, "null input relation");
     rhj_opts plan;
-    if (resolve_plan(nR, nS, opts, &plan) != RHJ_OK) return fail(ctx, RHJ_E_INVALID, "bad rhj_opts");
+    if (resolve_plan(nR, nS, opts, &plan, true) != RHJ_OK) return fail(ctx, RHJ_E_INVALID, "bad rhj_opts");
     RHJCHK(partition_and_join(ctx, d_R, nR, d_S, nS, plan, d_out, d_out ? out_capacity : 0, (u64 *)out_count));
     if (d_out && *out_count > out_capacity) return fail(ctx, RHJ_E_OVERFLOW, "result buffer too small");
     return RHJ_OK;

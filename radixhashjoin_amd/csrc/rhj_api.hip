@@ -69,6 +69,7 @@ struct rhj_ctx {
     int cur_radix_bits = 0;
     u32 cur_probe_split = 0;
     int last_join_kind = -1;
+    bool counters_clean = false;       // the 64-byte join counters are zero (cleared by the partition phase's first launch)
     int cur_narrow = 0;                // partitions are in the narrow {payload, rowID} format (k_scatter_wcn); 2: so was the intermediate
     DevBuf narrow_flag;                // u32: a rowID >= 2^32 met a narrow scatter -> the join re-runs in the 16-byte format
     bool narrow_gave_up = false;       // ... and this context stops trying
@@ -349,6 +350,10 @@ int run_pass_pair(rhj_ctx *ctx, const void *d_R, u64 nR, void *outR, u64 *psR, c
         h.side[i] = PassSide{in[i], out[i], (u64 *)seg[i]->p, (u32 *)ust[i]->p, (u32 *)uh[i]->p, (u64 *)ub[i]->p, ps[i],
                              (u64 *)sc[i]->p, g};
     }
+    // the first launch also clears the join counters (one memset less in front of a join that is ~10 launches in all)
+    RHJCHK(ensure(ctx, ctx->counters, 64));
+    h.zero8 = (u64 *)ctx->counters.p;
+    ctx->counters_clean = true;
     static const int kinds[4] = {RHJ_K_AUX, RHJ_K_HIST, RHJ_K_SCAN, RHJ_K_SCATTER};
     for (int phase = 0; phase < 4; phase++) {
         Span s(ctx, kinds[phase]);
@@ -498,6 +503,7 @@ int partition_phase(rhj_ctx *ctx, const void *d_R, u64 nR, const void *d_S, u64 
     ctx->last.passes = plan.passes;
     ctx->last.bits1 = plan.bits1;
     ctx->last.bits2 = plan.bits2;
+    ctx->counters_clean = false;
     ctx->cur_narrow = narrow_level(ctx, nR, nS, plan);
     if (ctx->cur_narrow) {
         RHJCHK(ensure(ctx, ctx->narrow_flag, 64));
@@ -561,10 +567,11 @@ int join_phase_on(rhj_ctx *ctx, const void *d_Rp, const u64 *d_psR, u64 nR, cons
     RHJCHK(ensure(ctx, ctx->counters, 64));
     u64 *d_count = (u64 *)ctx->counters.p;
     u32 *d_ntasks = (u32 *)(d_count + 1);
-    {
+    if (!ctx->counters_clean) {                      // (a paired partition pass has cleared them already)
         Span s(ctx, RHJ_K_AUX);
         HIPCHK(ctx, hipMemsetAsync(ctx->counters.p, 0, 64, ctx->stream));
     }
+    ctx->counters_clean = false;
     ctx->last_join_kind = is_direct(ctx, nparts, nR, nS) ? -1 : kind;
     if (is_direct(ctx, nparts, nR, nS)) {
         Span s(ctx, RHJ_K_JOIN);                                     // small unpartitioned join: one launch, no task list
@@ -608,8 +615,9 @@ int join_phase(rhj_ctx *ctx, void *d_out, u64 cap, u64 *out_count)
 int partition_and_join(rhj_ctx *ctx, const void *d_R, u64 nR, const void *d_S, u64 nS, const rhj_opts &plan, void *d_out,
                        u64 cap, u64 *out_count)
 {
-    RHJCHK(partition_phase(ctx, d_R, nR, d_S, nS, plan));
-    int rc = join_phase(ctx, d_out, cap, out_count);
+    int rc = partition_phase(ctx, d_R, nR, d_S, nS, plan);
+    if (rc != RHJ_OK) { ctx->counters_clean = false; return rc; }
+    rc = join_phase(ctx, d_out, cap, out_count);
     if (rc != RHJ_RETRY_WIDE) return rc;
     ctx->narrow_gave_up = true;
     RHJCHK(partition_phase(ctx, d_R, nR, d_S, nS, plan));
@@ -625,7 +633,11 @@ static std::map<void *, size_t> g_pool_sizes;             // size of every live 
 int rhj_internal_use_device(rhj_ctx *ctx) { return use_device(ctx); }
 hipStream_t rhj_internal_stream(rhj_ctx *ctx) { return ctx->stream; }
 int rhj_internal_fail(rhj_ctx *ctx, int code, const char *msg) { return fail(ctx, code, msg); }
-void *rhj_internal_counters(rhj_ctx *ctx) { return ensure(ctx, ctx->counters, 64) == RHJ_OK ? ctx->counters.p : nullptr; }
+void *rhj_internal_counters(rhj_ctx *ctx)
+{
+    ctx->counters_clean = false;                     // the caller is about to use them as scratch
+    return ensure(ctx, ctx->counters, 64) == RHJ_OK ? ctx->counters.p : nullptr;
+}
 
 // =================================================================================================
 // C-ABI
@@ -1091,6 +1103,7 @@ static int reduce_to_host(rhj_ctx *ctx, uint64_t *host_out, void (*launch)(hipSt
                           const void *d_in, u64 n)
 {
     RHJCHK(ensure(ctx, ctx->counters, 64));
+    ctx->counters_clean = false;
     u64 *d_sum = (u64 *)ctx->counters.p + 4;
     HIPCHK(ctx, hipMemsetAsync(d_sum, 0, 8, ctx->stream));
     if (n) {

@@ -83,7 +83,7 @@ struct PassSide {
     u64 *scan_tmp;
     PassGeom g;
 };
-struct PassPairHost { PassSide side[2]; };
+struct PassPairHost { PassSide side[2]; u64 *zero8 = nullptr; /* eight 64-bit words cleared by the first launch, or null */ };
 void launch_pass_pair(hipStream_t st, const PassPairHost &h, int shift, int bits, int phase);
 constexpr int PASS_PAIR_MAX_BITS = 9;            // the write-combining scatter's range
 bool fused_two_pass_ok(int b1, int b2);

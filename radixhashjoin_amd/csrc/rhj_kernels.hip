@@ -118,13 +118,15 @@ struct PassRel {                      // one relation's side of a partition pass
 };
 struct PassPair { PassRel r[2]; };
 
-__global__ void k_init_single_segment2(PassPair a)
+// zero8 (optional): the eight 64-bit join counters, cleared here so that the join phase needs no memset of its own
+__global__ void k_init_single_segment2(PassPair a, u64 *__restrict__ zero8)
 {
     const PassRel &x = a.r[blockIdx.x];
     if (threadIdx.x == 0) {
         x.seg_start[0] = 0; x.seg_start[1] = x.n;
         x.unit_start[0] = 0; x.unit_start[1] = (u32)((x.n + x.L - 1) / x.L);
     }
+    if (zero8 != nullptr && blockIdx.x == 0 && threadIdx.x < 8) zero8[threadIdx.x] = 0;
 }
 
 // unit_start[s] = sum_{s'<s} ceil(size(s') / L), one workgroup, nseg arbitrary
@@ -1056,11 +1058,26 @@ k_part_max(const u64 *__restrict__ startR, const u64 *__restrict__ startS, u64 n
 __global__ void __launch_bounds__(1024)
 k_make_tasks(const u64 *__restrict__ startR, const u64 *__restrict__ startS, u64 nparts, u32 probe_split,
              JoinTask *__restrict__ tasks, u32 *__restrict__ ntasks, u32 max_tasks, u64 *__restrict__ stats,
-             u32 table_tuples)
+             u32 table_tuples, int own_max)
 {
     __shared__ u32 wsum[16];
     __shared__ u32 gbase;
+    __shared__ u64 wmax[2][16];
     const u64 k = (u64)blockIdx.x * 1024 + threadIdx.x;
+    u64 maxR = 0, maxS = 0;
+    if (own_max) {                                     // one workgroup covers every partition: k_part_max's job done here
+        u64 mr = k < nparts ? startR[k + 1] - startR[k] : 0, ms = k < nparts ? startS[k + 1] - startS[k] : 0;
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+            const u64 a = __shfl_down(mr, off, 64), b = __shfl_down(ms, off, 64);
+            mr = a > mr ? a : mr;
+            ms = b > ms ? b : ms;
+        }
+        if ((threadIdx.x & 63) == 0) { wmax[0][threadIdx.x >> 6] = mr; wmax[1][threadIdx.x >> 6] = ms; }
+        __syncthreads();
+        for (int i = 0; i < 16; i++) { maxR = wmax[0][i] > maxR ? wmax[0][i] : maxR; maxS = wmax[1][i] > maxS ? wmax[1][i] : maxS; }
+        if (threadIdx.x == 0) { stats[0] = maxR; stats[1] = maxS; }
+    } else { maxR = stats[0]; maxS = stats[1]; }
     u32 nt = 0, bis = 0;
     u64 pbeg = 0, plen = 0, bbeg = 0, blen = 0;
     if (k < nparts) {
@@ -1072,7 +1089,7 @@ k_make_tasks(const u64 *__restrict__ startR, const u64 *__restrict__ startS, u64
             // tables full of duplicates: long buckets that serialise the few probe lanes hitting them.  If the
             // balanced side fits one or two LDS tables, build on it instead: one-compare probes, same pairs.
             const u64 meanR = startR[nparts] / nparts + 1, meanS = startS[nparts] / nparts + 1;
-            const bool skewR = stats[0] > 16 * meanR, skewS = stats[1] > 16 * meanS;
+            const bool skewR = maxR > 16 * meanR, skewS = maxS > 16 * meanS;
             bool build_S = nr >= ns;
             if (skewS && !skewR && nr <= 2 * (u64)table_tuples) build_S = false;     // at most two build chunks
             if (skewR && !skewS && ns <= 2 * (u64)table_tuples) build_S = true;
@@ -1994,7 +2011,7 @@ void launch_pass_pair(hipStream_t st, const PassPairHost &h, int shift, int bits
     }
     if (mu == 0) return;
     if (phase == 0) {
-        hipLaunchKernelGGL(k_init_single_segment2, dim3(2), dim3(64), 0, st, a);
+        hipLaunchKernelGGL(k_init_single_segment2, dim3(2), dim3(64), 0, st, a, h.zero8);
     } else if (phase == 1) {
         hipLaunchKernelGGL(k_hist_units2, dim3(mu, 2), dim3(PART_THREADS), ((size_t)4 << bits), st, a, shift, bits);
     } else if (phase == 2) {
@@ -2101,12 +2118,15 @@ void launch_prefix(hipStream_t st, const u64 *d_hist, u64 nbins, u64 *d_start)
 void launch_make_tasks(hipStream_t st, const u64 *d_startR, const u64 *d_startS, u64 nparts, u32 probe_split,
                        JoinTask *d_tasks, u32 *d_ntasks, u32 max_tasks, u64 *d_stats, int kind)
 {
-    u64 g = (nparts + 255) / 256;
-    if (g > 1024) g = 1024;
-    hipLaunchKernelGGL(k_part_max, dim3((unsigned)g), dim3(256), 0, st, d_startR, d_startS, nparts, d_stats);   // d_stats zeroed by the caller
+    const int own_max = nparts <= 1024 ? 1 : 0;        // a single workgroup of k_make_tasks sees every partition
+    if (!own_max) {
+        u64 g = (nparts + 255) / 256;
+        if (g > 1024) g = 1024;
+        hipLaunchKernelGGL(k_part_max, dim3((unsigned)g), dim3(256), 0, st, d_startR, d_startS, nparts, d_stats);   // d_stats zeroed by the caller
+    }
     hipLaunchKernelGGL(k_make_tasks, dim3((unsigned)((nparts + 1023) / 1024)), dim3(1024), 0, st, d_startR, d_startS,
                        nparts, probe_split, d_tasks, d_ntasks, max_tasks, d_stats,
-                       join_table_tuples(kind));
+                       join_table_tuples(kind), own_max);
 }
 
 void launch_join(hipStream_t st, const void *d_R, const u64 *d_startR, const void *d_S, const u64 *d_startS,

@@ -41,7 +41,30 @@ def cpu_model():
     return "unknown"
 
 
-def cpu_baseline(sample_n, reps=3):
+def np_mix(z):
+    """splitmix64 step of SURVEY §8d on a numpy uint64 array (wrapping arithmetic)"""
+    import numpy as np
+    z = z + np.uint64(0x9E3779B97F4A7C15)
+    z = (z ^ (z >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)
+    z = (z ^ (z >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)
+    return z ^ (z >> np.uint64(31))
+
+
+def host_inputs(n, tuple_dtype, seed=42):
+    """host AoS relations of the SURVEY §8d generators (R[i] = {i, mix(i+1)}; counter-based uniform FK: S[j] =
+    {j, mix(1 + mix(j ^ seed) % n)}), made with numpy: the GPU legs of this file do not touch oracle/"""
+    import numpy as np
+    i = np.arange(n, dtype=np.uint64)
+    R = np.empty(n, dtype=tuple_dtype)
+    R["key"] = i
+    R["payload"] = np_mix(i + np.uint64(1))
+    S = np.empty(n, dtype=tuple_dtype)
+    S["key"] = i
+    S["payload"] = np_mix(np.uint64(1) + np_mix(i ^ np.uint64(seed)) % np.uint64(n))
+    return R, S
+
+
+def cpu_baseline(sample_n, reps=5):
     """SURVEY §8d protocol: the reference's pthread CPU path (oracle/_ref, compiled from the reference's own sources) on
     this host's cores, NUM_OF_THREADS = 8 (the reference's default) and = 1, one warm-up + median of `reps` runs each, on a
     bounded sample of the same workload family.  Falls back to the scalar oracle port where oracle/_ref is absent."""
@@ -132,10 +155,8 @@ def extras(eng, torch, dev, steps, which="all"):
     torch.cuda.empty_cache()
 
     # the drop-in as the reference calls it: host AoS in, one malloc'd result page out (PCIe inclusive, pageable memory)
-    from oracle import pyoracle                      # generators only (inputs); the join below is the HIP path
-    o = pyoracle.Oracle()
     n = 128_000_000 if which == "all" else 16_000_000
-    Rh, Sh = o.gen_R(n), o.gen_S_counter(n, n, 42)
+    Rh, Sh = host_inputs(n, rhj.TUPLE)
     eng.join(Rh[:1_000_000], Sh[:1_000_000])
     secs = []
     for _ in range(3):
@@ -204,7 +225,7 @@ def main():
     ap.add_argument("--bits2", type=int, default=8)
     ap.add_argument("--passes", type=int, default=2, choices=[1, 2], help="1: single pass of --bits1 bits (BASELINE config 2)")
     ap.add_argument("--dist", choices=["uniform", "zipf"], default="uniform")
-    ap.add_argument("--cpu-sample", type=int, default=64_000_000, help="rows per side of the CPU baseline sample (0 = skip)")
+    ap.add_argument("--cpu-sample", type=int, default=128_000_000, help="rows per side of the CPU baseline sample (0 = skip)")
     ap.add_argument("--no-extras", action="store_true", help="skip the other BASELINE configs / end-to-end legs (N == 1)")
     ap.add_argument("--extras", choices=["all", "small"], default="all", help="small: skip the 1B Zipf leg, 16M end-to-end")
     ap.add_argument("--no-verify", action="store_true")
@@ -262,7 +283,6 @@ def main():
     else:
         from radixhashjoin_amd.sharded import ShardedJoin
         sj = ShardedJoin(eng, dist.group.WORLD, local_opts=opts)
-        sj.collect_timings = True
 
         def step():
             return sj.join(R, n, S, n)
@@ -288,11 +308,19 @@ def main():
             for k in kt:
                 kt[k][0] += t[k]["ms"]
                 kt[k][1] += t[k]["launches"]
-    if world > 1:                                      # summed by the sharded driver over the engine calls of every step
-        for k in kt:
-            kt[k] = list(sj.kernel_ms.get(k, [0.0, 0]))
     barrier()
     dt = time.perf_counter() - t0
+    if world > 1:
+        # per-kernel device time of the sharded path: `steps` MORE steps, outside the timed region (reading the HIP events of
+        # an engine call synchronises after it, which the timed steps must not do)
+        sj.collect_timings = True
+        sj.kernel_ms = {}
+        for _ in range(args.steps):
+            cnt, res = step()
+        sj.collect_timings = False
+        for k in kt:
+            kt[k] = list(sj.kernel_ms.get(k, [0.0, 0]))
+        barrier()
     eng.set_profiling(False)
 
     # verification of the last step (outside the timed region): exact count + order-insensitive checksum
@@ -357,12 +385,17 @@ def main():
                                    + (f"2-pass ({args.bits1}+{args.bits2} bit)" if args.passes == 2 else f"1-pass ({args.bits1} bit)")
                                    + " radix, inputs and pairs resident in HBM",
                        "tuples_R_global": nglobal, "tuples_S_global": nglobal, "matches_last_step_rank0": cnt,
-                       "exchange": "none (single GPU)" if world == 1 else "RCCL all-to-all by balanced owner class ranges"},
+                       "exchange": "none (single GPU)" if world == 1 else
+                                   sj.transport() + " by balanced owner class ranges, wire format " +
+                                   {"narrow12": "{payload 8 B, shard-local rowID 4 B}", "tuple16": "16-byte tuples"}[sj.stats["format"]]},
             "roofline": {"bound": "hbm",
                          "kernel": ("k_scatter_wcn" if narrow else "k_scatter_wc")
                                    + " (line-aligned write-combining scatter-partition, one pass over one relation)",
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": traffic, "algorithmic_bytes_per_launch": SCATTER_BYTES_PER_TUPLE * tuples_per_launch,
+                         "traffic": traffic,
+                         "traffic_replayed_from": "profiles/traffic.json (two rocprofv3 --pmc passes of this command, FETCH_SIZE and "
+                                                  "WRITE_SIZE, taken by profiles/run_profile.sh; not measured by this run)" if traffic else None,
+                         "algorithmic_bytes_per_launch": SCATTER_BYTES_PER_TUPLE * tuples_per_launch,
                          "avg_launch_ms": sc_ms,
                          "intermediate_format": {0: "16 B tuples", 1: "16 B tuples, then {payload 8 B, rowID 4 B} partitions",
                                                  2: "{payload 8 B, rowID 4 B} arrays after both passes"}[narrow],
@@ -377,6 +410,13 @@ def main():
                                ((24.0 if narrow else 32.0) + 16.0) * n / (kt["join"][0] / max(kt["join"][1], 1) * 1e-3) / 1e9
                                if kt["join"][0] else 0.0,
                                "hist (16 B per tuple)": 16.0 * n / (kt["hist"][0] / max(kt["hist"][1], 1) * 1e-3) / 1e9 if kt["hist"][0] else 0.0}
+        if world > 1:
+            line["sharded"] = {"wire_format": sj.stats["format"], "exchange_bytes_per_rank": sj.stats["exchange_bytes_sent"],
+                               "bytes_per_tuple_sent": {"narrow12": 12, "tuple16": 16}[sj.stats["format"]],
+                               "recv_tuples_rank0": [sj.stats["recv_R"], sj.stats["recv_S"]],
+                               "local_plan": sj.stats.get("plan"), "backend": dist.get_backend(),
+                               "kernel_ms_per_step_rank0": {k: v[0] / args.steps for k, v in kt.items()},
+                               "kernel_ms_note": "device time of rank 0's kernels, from extra steps outside the timed region"}
         if auto is not None:
             line["auto_plan"] = auto
         else:

@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define RHJ_ABI_VERSION 1
+#define RHJ_ABI_VERSION 2
 
 /* layout-identical to `struct tuple` (structs.h:33-36): key = rowID, payload = join value */
 typedef struct { uint64_t key; uint64_t payload; } rhj_tuple;
@@ -149,6 +149,50 @@ int rhj_partition_at(rhj_ctx *ctx, const rhj_tuple *d_in, uint64_t n, int shift,
 int rhj_bucket_join(rhj_ctx *ctx, const rhj_tuple *d_Rp, const uint64_t *d_startR,
                     const rhj_tuple *d_Sp, const uint64_t *d_startS, uint64_t nparts, int radix_bits,
                     int probe_split, rhj_pair *d_out, uint64_t out_capacity, uint64_t *out_count);
+
+/* ---- multi-GPU stage entry points (the reference has no distributed path) -------------------
+ * One process per GPU; both relations range-sharded by row (structs.cpp:146-161 applied across GPUs instead of threads).
+ * These calls are the COMPUTE of a sharded join; the two collectives between them (an all-gather of the class
+ * histograms, an all-to-all of the tuples over RCCL / xGMI) belong to the host, which may be C++ with rccl.h or Python
+ * with torch.distributed (radixhashjoin_amd/sharded.py runs exactly this schedule):
+ *
+ *   1. rhj_shard_stats  (R, side 0), (S, side 1)     class histogram of the shard at payload bits [shift, shift+bits) and the
+ *                                                    range of its rowIDs                                   [16 B/tuple read]
+ *   2. all-gather {histograms, rowID ranges}  ->  every rank derives the same contiguous class range per owner and its
+ *      send / receive counts; key_base = the shard's smallest rowID (the narrow wire format needs max - min < 2^32)
+ *   3. rhj_shard_split  per relation                 class split straight into the NARROW WIRE FORMAT:
+ *         payloads  uint64[n]  at d_narrow_out                      (8 B/tuple)
+ *         rowIDs    uint32[n]  at d_narrow_out + rhj_narrow_key_offset(n), value = rowID - key_base   (4 B/tuple)
+ *      tuples of one class contiguous, classes in order: 12 B/tuple cross xGMI instead of 16      [16 B read + 12 B written]
+ *   4. all-to-all of the payload array and of the rowID array (same element counts; destination d gets classes
+ *      [cut[d], cut[d+1]))
+ *   5. rhj_shard_partition per relation              the local fused two-pass radix partition of what arrived (one histogram
+ *      read of the payloads, two narrow scatter passes).  The receive buffer is nseg sender segments: pass-1 units are cut
+ *      at the segment boundaries, and pass 2 stamps every tuple with its sender (low 4 payload bits, dead by then)
+ *   6. rhj_shard_join                                bucket join of the two partitioned sides (Result.cpp:43-76 per bucket);
+ *      a pair reports row0[sender] + local rowID for both sides: global rowIDs, as if one GPU had joined everything.
+ * Results stay sharded (every rank holds the pairs of the join values it owns).
+ * rhj_shard_plan says whether sizes / plan fit this path (1) or the host must fall back to exchanging 16-byte tuples (0):
+ * rhj_partition_at + all-to-all + rhj_join_dev. */
+uint64_t rhj_narrow_key_offset(uint64_t n);               /* byte offset of the rowID array inside a narrow buffer of n tuples */
+uint64_t rhj_narrow_bytes(uint64_t n);                    /* bytes of a narrow buffer of n tuples (<= 16 n for n >= 1024) */
+int rhj_shard_plan(uint64_t nR, uint64_t nS, const rhj_opts *in, rhj_opts *resolved);   /* 1 / 0 / negative rhj_status */
+/* hist: HOST array of 2^bits counts; key_min / key_max: HOST words (may be NULL).  Synchronises.  side: 0 or 1 -- two sets of
+ * unit tables, so that R and S can both be between their rhj_shard_stats and their rhj_shard_split. */
+int rhj_shard_stats(rhj_ctx *ctx, int side, const rhj_tuple *d_rel, uint64_t n, int shift, int bits, uint64_t *hist,
+                    uint64_t *key_min, uint64_t *key_max);
+/* asynchronous; d_narrow_out has rhj_narrow_bytes(n) bytes; d_class_start (device, 2^bits + 1, may be NULL) gets the class
+ * boundaries inside the output.  Same d_rel / n / shift / bits as the rhj_shard_stats call of this side. */
+int rhj_shard_split(rhj_ctx *ctx, int side, const rhj_tuple *d_rel, uint64_t n, int shift, int bits, uint64_t key_base,
+                    void *d_narrow_out, uint64_t *d_class_start);
+/* asynchronous; seg_off: HOST array of nseg + 1 offsets into the received arrays (seg_off[0] = 0, seg_off[nseg] = m),
+ * segment s = what rank s sent; plan: a resolved two-pass plan for which rhj_shard_plan returned 1 (same on both sides) */
+int rhj_shard_partition(rhj_ctx *ctx, int side, const uint64_t *d_payloads, const uint32_t *d_rowids, uint64_t m, int nseg,
+                        const uint64_t *seg_off, const rhj_opts *plan);
+/* row0_R / row0_S: HOST arrays of nseg rowID bases (the key_base each rank split its shard with).  Count / overflow
+ * behaviour of rhj_join_dev. */
+int rhj_shard_join(rhj_ctx *ctx, int nseg, const uint64_t *row0_R, const uint64_t *row0_S, rhj_pair *d_out, uint64_t out_capacity,
+                   uint64_t *out_count);
 
 /* ---- utilities -------------------------------------------------------------------------- */
 /* order-insensitive checksum of SURVEY.md App. A over a device pair array:

@@ -71,6 +71,13 @@ SYMBOLS = {
     "rhj_partition": (C.c_int, [_vp, _vp, _u64, C.c_int, C.c_int, _vp, _vp]),
     "rhj_partition_at": (C.c_int, [_vp, _vp, _u64, C.c_int, C.c_int, _vp, _vp]),
     "rhj_bucket_join": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _u64, C.c_int, C.c_int, _vp, _u64, _P(_u64)]),
+    "rhj_narrow_key_offset": (_u64, [_u64]),
+    "rhj_narrow_bytes": (_u64, [_u64]),
+    "rhj_shard_plan": (C.c_int, [_u64, _u64, _P(Opts), _P(Opts)]),
+    "rhj_shard_stats": (C.c_int, [_vp, C.c_int, _vp, _u64, C.c_int, C.c_int, _vp, _P(_u64), _P(_u64)]),
+    "rhj_shard_split": (C.c_int, [_vp, C.c_int, _vp, _u64, C.c_int, C.c_int, _u64, _vp, _vp]),
+    "rhj_shard_partition": (C.c_int, [_vp, C.c_int, _vp, _vp, _u64, C.c_int, _vp, _P(Opts)]),
+    "rhj_shard_join": (C.c_int, [_vp, C.c_int, _vp, _vp, _vp, _u64, _P(_u64)]),
     "rhj_pairs_checksum_dev": (C.c_int, [_vp, _vp, _u64, _P(_u64)]),
     "rhj_generate_dev": (C.c_int, [_vp, C.c_int, _vp, _u64, _u64, _u64, _u64, C.c_int]),
     "rhj_expected_pkfk_dev": (C.c_int, [_vp, _vp, _u64, _P(_u64), _P(_u64)]),
@@ -113,6 +120,25 @@ def plan(nR, nS, opts=None):
     if rc != RHJ_OK:
         raise RhjError(rc, "bad options")
     return out
+
+
+def narrow_key_offset(n):
+    """byte offset of the rowID array in a narrow buffer of n tuples (include/rhj.h, multi-GPU wire format)"""
+    return load_library().rhj_narrow_key_offset(n)
+
+
+def narrow_bytes(n):
+    return load_library().rhj_narrow_bytes(n)
+
+
+def shard_plan(nR, nS, opts=None):
+    """(ok, plan): ok = the narrow sharded path (rhj_shard_*) serves a local join of these sizes under `plan`"""
+    lib = load_library()
+    out = Opts()
+    rc = lib.rhj_shard_plan(nR, nS, C.byref(opts) if opts is not None else None, C.byref(out))
+    if rc < 0:
+        raise RhjError(rc, "bad options")
+    return rc == 1, out
 
 
 def _addr(x):
@@ -298,6 +324,32 @@ class Engine:
         n = _u64()
         rc = self.lib.rhj_bucket_join(self.ctx, _addr(d_Rp), _addr(d_startR), _addr(d_Sp), _addr(d_startS), nparts,
                                       radix_bits, probe_split, _addr(d_out), capacity, C.byref(n))
+        self._chk(rc, allow=(RHJ_E_OVERFLOW,) if allow_overflow else ())
+        return n.value
+
+    # ---- multi-GPU stage entry points (include/rhj.h) --------------------------------------
+    def shard_stats(self, side, d_rel, n, shift, bits):
+        """class histogram (numpy int64 [2^bits]) and rowID range (min, max) of a shard; synchronises"""
+        hist = np.zeros(1 << bits, dtype=np.uint64)
+        kmin, kmax = _u64(), _u64()
+        self._chk(self.lib.rhj_shard_stats(self.ctx, side, _addr(d_rel), n, shift, bits, hist.ctypes.data, C.byref(kmin), C.byref(kmax)))
+        return hist.astype(np.int64), kmin.value, kmax.value
+
+    def shard_split(self, side, d_rel, n, shift, bits, key_base, d_narrow_out, d_class_start=None):
+        self._chk(self.lib.rhj_shard_split(self.ctx, side, _addr(d_rel), n, shift, bits, key_base, _addr(d_narrow_out),
+                                           _addr(d_class_start)))
+
+    def shard_partition(self, side, d_payloads, d_rowids, m, seg_off, plan):
+        seg = (C.c_uint64 * len(seg_off))(*[int(x) for x in seg_off])
+        self._chk(self.lib.rhj_shard_partition(self.ctx, side, _addr(d_payloads), _addr(d_rowids), m, len(seg_off) - 1, seg,
+                                               C.byref(plan)))
+
+    def shard_join(self, row0_R, row0_S, d_out=None, capacity=0, allow_overflow=False):
+        assert len(row0_R) == len(row0_S)
+        a = (C.c_uint64 * len(row0_R))(*[int(x) for x in row0_R])
+        b = (C.c_uint64 * len(row0_S))(*[int(x) for x in row0_S])
+        n = _u64()
+        rc = self.lib.rhj_shard_join(self.ctx, len(row0_R), a, b, _addr(d_out), capacity, C.byref(n))
         self._chk(rc, allow=(RHJ_E_OVERFLOW,) if allow_overflow else ())
         return n.value
 

@@ -52,7 +52,8 @@ struct rhj_ctx {
     DevBuf out_pairs;                  // rhj_join's device result buffer
     DevBuf small_out;                  // small-join path: 64-byte header {count} + pairs, fetched in one D2H
     bool small_hdr_clean = false;      // the header has been zeroed behind the previous small join
-    DevBuf hist_tmp, scan_tmp, hist2, grp_rng, unit_start2;
+    DevBuf hist_tmp, scan_tmp, hist2, grp_rng, unit_start2, seg_rng, tag_base;
+    DevBuf shard_ps[2], shard_mm;      // multi-GPU sender: class boundaries per side, rowID {min, max} per side
     // rhj_dev_alloc / rhj_dev_free keep released blocks for re-use (all work of a context is ordered on its one
     // stream, so a block may be handed out again while kernels that used it are still queued): a device-resident
     // query allocates and frees a dozen arrays per join, and hipMalloc/hipFree would synchronise every time
@@ -72,7 +73,15 @@ struct rhj_ctx {
     bool counters_clean = false;       // the 64-byte join counters are zero (cleared by the partition phase's first launch)
     int cur_narrow = 0;                // partitions are in the narrow {payload, rowID} format (k_scatter_wcn); 2: so was the intermediate
     DevBuf narrow_flag;                // u32: a rowID >= 2^32 met a narrow scatter -> the join re-runs in the 16-byte format
-    bool narrow_gave_up = false;       // ... and this context stops trying
+    // ... the next join tries the narrow format again; consecutive fall-backs make the context skip the attempt for the next
+    // 2, 4, ... 32 eligible joins (a caller whose rowIDs are always wide pays one extra histogram per relation now and then)
+    u32 narrow_fail_streak = 0, narrow_skip = 0;
+    bool narrow_off_once = false;      // the repeat of a join that fell back
+    // multi-GPU receiver (rhj_shard_partition / rhj_shard_join): the partitions carry sender tags
+    int shard_nseg = 0;
+    bool shard_side_done[2] = {false, false};
+    u64 shard_n[2] = {0, 0}, shard_kmin[2] = {0, 0}, shard_kmax[2] = {0, 0};
+    rhj_opts shard_plan{};
     // pinned host landing zone of the small-join path: 64-byte header {count}, then up to 128 KiB of result pairs
     unsigned char *h_land = nullptr;
     unsigned char *h_land_dev = nullptr;   // the same memory as the device addresses it
@@ -205,8 +214,21 @@ void prof_reset(rhj_ctx *ctx)
 int check_launch(rhj_ctx *ctx, const char *what)
 {
     hipError_t e = hipGetLastError();
+    if (const char *attr = launch_attr_error())          // a kernel was refused its LDS size: say so instead of "invalid argument"
+        return fail(ctx, RHJ_E_HIP, std::string(what) + ": " + attr);
     if (e != hipSuccess) return fail(ctx, RHJ_E_HIP, std::string(what) + " launch: " + hipGetErrorString(e));
     return RHJ_OK;
+}
+
+// tuning environment variables: unset, empty or non-numeric -> the default; numeric values are clamped to [lo, hi]
+u64 env_u64(const char *name, u64 dflt, u64 lo, u64 hi)
+{
+    const char *v = getenv(name);
+    if (!v || !*v) return dflt;
+    char *end = nullptr;
+    const u64 x = strtoull(v, &end, 10);
+    if (end == v) return dflt;
+    return x < lo ? lo : x > hi ? hi : x;
 }
 
 int ilog2_ceil(u64 x)
@@ -278,7 +300,7 @@ PassGeom make_geom(u64 n, u32 nseg, int shift, int bits, u64 target_units = PART
 {
     PassGeom g;
     g.n = n;
-    static const u64 forced_units = getenv("RHJ_UNITS") ? strtoull(getenv("RHJ_UNITS"), nullptr, 10) : 0;   // tuning aid
+    static const u64 forced_units = env_u64("RHJ_UNITS", 0, 1, 65536);                                   // tuning aid
     if (forced_units) target_units = forced_units;
     u64 L = (n + target_units - 1) / target_units;
     L = (L + PART_TILE - 1) / PART_TILE * PART_TILE;
@@ -365,15 +387,45 @@ int run_pass_pair(rhj_ctx *ctx, const void *d_R, u64 nR, void *outR, u64 *psR, c
 // Two passes with ONE histogram read (k_hist2d_units): used when both passes fit the write-combining scatter
 // and b1 + b2 <= 16.  Pass-2 units = pieces of each pass-1 bucket written by groups of pass-1 units.
 // narrow: 0 = 16-byte tuples throughout; 1 = pass 2 writes the narrow format (what the join kernel then reads); 2 = pass 1 too
-int partition_relation_fused(rhj_ctx *ctx, const void *d_in, u64 n, int b1, int b2, void *d_out, u64 *d_ps, int narrow = 0)
+// Input: 16-byte tuples (in.aos), or -- the multi-GPU receiver -- narrow arrays that arrived in nseg sender segments
+// (in.P / in.K / in.seg_off; narrow is then 2): pass-1 units are cut at the segment boundaries and pass 2 writes the sender
+// number into the low payload bits (k_scatter_wcn's WnTag), which the join kernels resolve into global rowIDs.
+struct FusedIn {
+    const void *aos = nullptr;
+    const u64 *P = nullptr;
+    const u32 *K = nullptr;
+    int nseg = 0;
+    const u64 *seg_off = nullptr;      // host, nseg + 1
+};
+
+int partition_relation_fused(rhj_ctx *ctx, const FusedIn &in, u64 n, int b1, int b2, void *d_out, u64 *d_ps, int narrow = 0)
 {
+    const bool segs = in.P != nullptr;
     // 1024 pass-1 units instead of 2048: every unit flushes a 2^(b1+b2)-bin table, and the scatter does not care
     // ([measured] at 10^9 tuples: histogram 2.54 against 2.74 ms, scatter within noise)
     const PassGeom g1 = make_geom(n, 1, 0, b1, PART_TARGET_UNITS / 2);
-    const u32 units1 = (u32)((n + g1.L - 1) / g1.L);
-    static const u32 want_groups = getenv("RHJ_GROUPS") ? (u32)atoi(getenv("RHJ_GROUPS")) : 16u;   // tuning aid
-    const u32 per = units1 ? (units1 + want_groups - 1) / want_groups : 1;
-    const u32 ngroups = units1 ? (units1 + per - 1) / per : 1;
+    static const u32 want_groups = (u32)env_u64("RHJ_GROUPS", 16, 1, 64);                          // tuning aid
+    u32 units1, per, ngroups, groups_per_seg = 0;
+    u64 segL[16] = {0};
+    if (segs) {
+        if (in.nseg < 1 || in.nseg > seg_max() || narrow != 2 || b1 < tag_bits())
+            return fail(ctx, RHJ_E_INVALID, "segmented input: 1..16 segments, narrow format, pass 1 of at least 4 bits");
+        groups_per_seg = want_groups / (u32)in.nseg ? want_groups / (u32)in.nseg : 1u;
+        ngroups = groups_per_seg * (u32)in.nseg;
+        per = (u32)(PART_TARGET_UNITS / 2) / ngroups ? (u32)(PART_TARGET_UNITS / 2) / ngroups : 1u;
+        const u32 units_per_seg = groups_per_seg * per;
+        units1 = units_per_seg * (u32)in.nseg;
+        for (int s_ = 0; s_ < in.nseg; s_++) {
+            const u64 len = in.seg_off[s_ + 1] - in.seg_off[s_];
+            u64 L = (len + units_per_seg - 1) / units_per_seg;
+            L = (L + PART_TILE - 1) / PART_TILE * PART_TILE;
+            segL[s_] = L ? L : (u64)PART_TILE;
+        }
+    } else {
+        units1 = (u32)((n + g1.L - 1) / g1.L);
+        per = units1 ? (units1 + want_groups - 1) / want_groups : 1;
+        ngroups = units1 ? (units1 + per - 1) / per : 1;
+    }
     const size_t nb1 = (size_t)1 << b1, nb2 = (size_t)1 << b2;
     const u32 units2 = (u32)(nb1 * ngroups);
     RHJCHK(ensure(ctx, ctx->seg0, 64));
@@ -386,29 +438,39 @@ int partition_relation_fused(rhj_ctx *ctx, const void *d_in, u64 n, int b1, int 
     RHJCHK(ensure(ctx, ctx->unit_start2, (nb1 + 1) * 4));
     RHJCHK(ensure(ctx, ctx->part_tmp, (size_t)(n ? n : 1) * 16));
     RHJCHK(ensure(ctx, ctx->ps_1, (nb1 + 1) * 8));
+    if (segs) RHJCHK(ensure(ctx, ctx->seg_rng, ((size_t)units1 + 1) * 8));
     u64 *seg0 = (u64 *)ctx->seg0.p;
     u32 *unit_start1 = (u32 *)ctx->unit_start.p;
+    const u64 *rng1 = segs ? (const u64 *)ctx->seg_rng.p : nullptr;
+    u32 *wide = narrow ? (u32 *)ctx->narrow_flag.p : nullptr;
+    PassGeom gs = g1;                                   // (segmented: the scan only needs the unit count)
+    gs.max_units = units1;
     {
         Span s(ctx, RHJ_K_AUX);
-        launch_init_single_segment(ctx->stream, n, g1.L, seg0, unit_start1);          // seg0 = {0,n}, unit_start1 = {0, units1}
+        if (segs) launch_seg_units(ctx->stream, (u32)in.nseg, in.seg_off, segL, groups_per_seg * per, (u64 *)ctx->seg_rng.p, seg0, unit_start1);
+        else launch_init_single_segment(ctx->stream, n, g1.L, seg0, unit_start1);          // seg0 = {0,n}, unit_start1 = {0, units1}
         HIPCHK(ctx, hipMemsetAsync(ctx->hist2.p, 0, (size_t)units2 * nb2 * 4, ctx->stream));
     }
     {
-        Span s(ctx, RHJ_K_HIST);
-        launch_hist2d_units(ctx->stream, d_in, n, g1.L, units1, b1, b2, per, ngroups, (u32 *)ctx->unit_hist.p, (u32 *)ctx->hist2.p);
+        Span s(ctx, RHJ_K_HIST);                        // (16-byte input: also reports a rowID that does not fit the narrow format)
+        launch_hist2d_units(ctx->stream, segs ? (const void *)in.P : in.aos, segs, n, g1.L, units1, b1, b2, per, ngroups,
+                            (u32 *)ctx->unit_hist.p, (u32 *)ctx->hist2.p, 0, wide, rng1);
     }
     {
         Span s(ctx, RHJ_K_SCAN);
-        launch_scan_units(ctx->stream, g1, seg0, unit_start1, (const u32 *)ctx->unit_hist.p, (u64 *)ctx->unit_base.p,
+        launch_scan_units(ctx->stream, gs, seg0, unit_start1, (const u32 *)ctx->unit_hist.p, (u64 *)ctx->unit_base.p,
                           (u64 *)ctx->ps_1.p, (u64 *)ctx->scan_tmp.p);
     }
     {
         Span s(ctx, RHJ_K_SCATTER);
-        if (narrow == 2)
-            launch_scatter_units_narrow(ctx->stream, d_in, ctx->part_tmp.p, n, g1, seg0, unit_start1, (const u64 *)ctx->unit_base.p,
-                                        (u32 *)ctx->narrow_flag.p);
+        if (segs)
+            launch_scatter_ranges_narrow(ctx->stream, in.P, true, ctx->part_tmp.p, n, units1, 0, b1, (const u64 *)ctx->unit_base.p,
+                                         rng1, wide, 0, 0, in.K);
+        else if (narrow == 2)
+            launch_scatter_units_narrow(ctx->stream, in.aos, ctx->part_tmp.p, n, g1, seg0, unit_start1, (const u64 *)ctx->unit_base.p,
+                                        wide);
         else
-            launch_scatter_units(ctx->stream, d_in, ctx->part_tmp.p, g1, seg0, unit_start1, (const u64 *)ctx->unit_base.p);
+            launch_scatter_units(ctx->stream, in.aos, ctx->part_tmp.p, g1, seg0, unit_start1, (const u64 *)ctx->unit_base.p);
     }
     {
         Span s(ctx, RHJ_K_AUX);
@@ -426,12 +488,20 @@ int partition_relation_fused(rhj_ctx *ctx, const void *d_in, u64 n, int b1, int 
         Span s(ctx, RHJ_K_SCATTER);
         if (narrow)
             launch_scatter_ranges_narrow(ctx->stream, ctx->part_tmp.p, narrow == 2, d_out, n, units2, b1, b2,
-                                         (const u64 *)ctx->unit_base.p, (const u64 *)ctx->grp_rng.p, (u32 *)ctx->narrow_flag.p);
+                                         (const u64 *)ctx->unit_base.p, (const u64 *)ctx->grp_rng.p, wide,
+                                         segs ? ngroups : 0u, segs ? groups_per_seg : 0u);
         else
             launch_scatter_ranges(ctx->stream, ctx->part_tmp.p, d_out, units2, b1, b2, (const u64 *)ctx->unit_base.p,
                                   (const u64 *)ctx->grp_rng.p);
     }
     return check_launch(ctx, "fused two-pass partition");
+}
+
+int partition_relation_fused(rhj_ctx *ctx, const void *d_in, u64 n, int b1, int b2, void *d_out, u64 *d_ps, int narrow = 0)
+{
+    FusedIn in;
+    in.aos = d_in;
+    return partition_relation_fused(ctx, in, n, b1, b2, d_out, d_ps, narrow);
 }
 
 // Partition one relation with `passes` passes into d_out; boundaries into d_ps[2^(b1+b2) + 1].
@@ -471,9 +541,10 @@ int choose_join_kind(const rhj_ctx *ctx, u64 nR, u64 nS, u64 nparts, int radix_b
 // found out on the device).  Returns the level (0 = not at all).
 int narrow_level(const rhj_ctx *ctx, u64 nR, u64 nS, const rhj_opts &plan)
 {
-    static const int env = getenv("RHJ_NARROW") ? atoi(getenv("RHJ_NARROW")) : 2;
+    static const int env = (int)env_u64("RHJ_NARROW", 2, 0, 2);
     const int want = ctx->opt_narrow >= 0 ? ctx->opt_narrow : env;
-    if (want <= 0 || ctx->narrow_gave_up || plan.passes != 2 || !fused_two_pass_ok(plan.bits1, plan.bits2)) return 0;
+    if (want <= 0 || ctx->narrow_off_once || plan.passes != 2 || !fused_two_pass_ok(plan.bits1, plan.bits2)) return 0;
+    if (ctx->opt_narrow < 0 && ctx->narrow_skip > 0) return 0;              // backing off after repeated wide rowIDs (automatic mode only)
     if (!narrow_pass_ok(plan.bits1) || !narrow_pass_ok(plan.bits2)) return 0;
     const u64 lo = nR < nS ? nR : nS, hi = nR < nS ? nS : nR;
     if (lo < NARROW_MIN_TUPLES || hi >= ((u64)1 << 32)) return 0;
@@ -482,7 +553,7 @@ int narrow_level(const rhj_ctx *ctx, u64 nR, u64 nS, const rhj_opts &plan)
     if (kind != JK_CT && kind != JK_CT_HALF && kind != JK_BKT) return 0;
     // the narrow scatter has one 1024-thread workgroup per CU and 32-tuple lines to start and finish per digit and unit:
     // below a few million tuples its fixed costs outweigh the bytes it saves (forced levels, used by the tests, skip this)
-    static const u64 min_auto = getenv("RHJ_NARROW_MIN") ? strtoull(getenv("RHJ_NARROW_MIN"), nullptr, 10) : NARROW_AUTO_MIN_TUPLES;
+    static const u64 min_auto = env_u64("RHJ_NARROW_MIN", NARROW_AUTO_MIN_TUPLES, 0, ~0ull);
     if (ctx->opt_narrow < 0 && hi < min_auto) return 0;
     return want >= 2 ? 2 : 1;
 }
@@ -550,8 +621,11 @@ int partition_phase(rhj_ctx *ctx, const void *d_R, u64 nR, const void *d_S, u64 
 }
 
 // Join phase on explicit partitioned inputs.  Synchronises to read the exact result count.
+// narrow: the partitions are narrow arrays; tag_base (device, 2 x 16 u64; narrow only): the low payload bits name the sender
+// of a tuple and rowIDs are local to it (multi-GPU receiver).  allow_direct: the boundaries are known to be {0, n}.
 int join_phase_on(rhj_ctx *ctx, const void *d_Rp, const u64 *d_psR, u64 nR, const void *d_Sp, const u64 *d_psS,
-                  u64 nS, u64 nparts, int radix_bits, u32 probe_split, void *d_out, u64 cap, u64 *out_count, bool narrow = false)
+                  u64 nS, u64 nparts, int radix_bits, u32 probe_split, void *d_out, u64 cap, u64 *out_count, bool narrow = false,
+                  const u64 *d_tag_base = nullptr, bool allow_direct = true, bool check_radix = false)
 {
     if (probe_split == 0) probe_split = 32768;
     // a task addresses its build range with 32 bits; k_make_tasks reports any partition whose build side is larger
@@ -572,8 +646,13 @@ int join_phase_on(rhj_ctx *ctx, const void *d_Rp, const u64 *d_psR, u64 nR, cons
         HIPCHK(ctx, hipMemsetAsync(ctx->counters.p, 0, 64, ctx->stream));
     }
     ctx->counters_clean = false;
-    ctx->last_join_kind = is_direct(ctx, nparts, nR, nS) ? -1 : kind;
-    if (is_direct(ctx, nparts, nR, nS)) {
+    const bool direct = allow_direct && !narrow && is_direct(ctx, nparts, nR, nS);
+    ctx->last_join_kind = direct ? -1 : kind;
+    if (check_radix && !direct && (kind == JK_CT || kind == JK_CT_HALF)) {       // counters[6]: the partitions break the radix_bits contract
+        Span s(ctx, RHJ_K_AUX);
+        launch_check_radix(ctx->stream, d_Rp, d_psR, d_Sp, d_psS, nparts, radix_bits, d_count + 6);
+    }
+    if (direct) {
         Span s(ctx, RHJ_K_JOIN);                                     // small unpartitioned join: one launch, no task list
         launch_join_direct(ctx->stream, d_Rp, nR, d_Sp, nS, d_out, d_out ? cap : 0, d_count);
     } else {
@@ -587,11 +666,12 @@ int join_phase_on(rhj_ctx *ctx, const void *d_Rp, const u64 *d_psR, u64 nR, cons
             launch_join(ctx->stream, d_Rp, d_psR, d_Sp, d_psS, (const JoinTask *)ctx->tasks.p, d_ntasks, max_tasks,
                         radix_bits, d_out, d_out ? cap : 0, d_count, kind,
                         narrow ? (const u32 *)((const unsigned char *)d_Rp + narrow_k_offset(nR)) : nullptr,
-                        narrow ? (const u32 *)((const unsigned char *)d_Sp + narrow_k_offset(nS)) : nullptr);
+                        narrow ? (const u32 *)((const unsigned char *)d_Sp + narrow_k_offset(nS)) : nullptr,
+                        d_tag_base, narrow ? (const u32 *)ctx->narrow_flag.p : nullptr);
         }
     }
     RHJCHK(check_launch(ctx, "join phase"));
-    u64 host[6] = {0, 0, 0, 0, 0, 0};          // count, ntasks, max |R_k|, max |S_k|, (checksum scratch), oversized build side
+    u64 host[7] = {0, 0, 0, 0, 0, 0, 0};       // count, ntasks, max |R_k|, max |S_k|, (checksum scratch), oversized build side, contract
     u32 wide_rowid = 0;
     HIPCHK(ctx, hipMemcpyAsync(host, ctx->counters.p, sizeof(host), hipMemcpyDeviceToHost, ctx->stream));
     if (narrow) HIPCHK(ctx, hipMemcpyAsync(&wide_rowid, ctx->narrow_flag.p, 4, hipMemcpyDeviceToHost, ctx->stream));
@@ -602,6 +682,9 @@ int join_phase_on(rhj_ctx *ctx, const void *d_Rp, const u64 *d_psR, u64 nR, cons
     if (host[5])
         return fail(ctx, RHJ_E_INVALID, "a partition's build side has " + std::to_string(host[5]) +
                                         " tuples (>= 2^32): use more radix bits");
+    if (host[6])
+        return fail(ctx, RHJ_E_INVALID, "rhj_bucket_join: the payloads of a partition do not share their low radix_bits bits "
+                                        "(radix_bits must be the number of low payload bits that are constant inside every partition)");
     return RHJ_OK;
 }
 
@@ -611,16 +694,26 @@ int join_phase(rhj_ctx *ctx, void *d_out, u64 cap, u64 *out_count)
                          ctx->cur_nparts, ctx->cur_radix_bits, ctx->cur_probe_split, d_out, cap, out_count, ctx->cur_narrow != 0);
 }
 
-// partition + join; a run in the narrow format that met a rowID >= 2^32 is repeated in the 16-byte format
+// partition + join.  A run in the narrow format whose histogram kernel met a rowID >= 2^32 costs two histogram launches
+// (every later kernel of the run returns at once) and is repeated in the 16-byte format; the fall-back is per join.
 int partition_and_join(rhj_ctx *ctx, const void *d_R, u64 nR, const void *d_S, u64 nS, const rhj_opts &plan, void *d_out,
                        u64 cap, u64 *out_count)
 {
     int rc = partition_phase(ctx, d_R, nR, d_S, nS, plan);
     if (rc != RHJ_OK) { ctx->counters_clean = false; return rc; }
+    const bool tried_narrow = ctx->cur_narrow != 0;
+    if (!tried_narrow && ctx->narrow_skip > 0 && plan.passes == 2) ctx->narrow_skip--;
     rc = join_phase(ctx, d_out, cap, out_count);
-    if (rc != RHJ_RETRY_WIDE) return rc;
-    ctx->narrow_gave_up = true;
-    RHJCHK(partition_phase(ctx, d_R, nR, d_S, nS, plan));
+    if (rc != RHJ_RETRY_WIDE) {
+        if (rc == RHJ_OK && tried_narrow) ctx->narrow_fail_streak = 0;
+        return rc;
+    }
+    ctx->narrow_fail_streak++;
+    ctx->narrow_skip = ctx->narrow_fail_streak < 2 ? 0u : (ctx->narrow_fail_streak > 5 ? 32u : 1u << (ctx->narrow_fail_streak - 1));
+    ctx->narrow_off_once = true;
+    rc = partition_phase(ctx, d_R, nR, d_S, nS, plan);
+    ctx->narrow_off_once = false;
+    if (rc != RHJ_OK) { ctx->counters_clean = false; return rc; }
     return join_phase(ctx, d_out, cap, out_count);
 }
 
@@ -701,7 +794,8 @@ int rhj_release_workspace(rhj_ctx *ctx)
                      &ctx->ps_1, &ctx->seg0, &ctx->unit_start, &ctx->unit_hist, &ctx->unit_base, &ctx->seg0_b,
                      &ctx->unit_start_b, &ctx->unit_hist_b, &ctx->unit_base_b, &ctx->scan_tmp_b, &ctx->tasks,
                      &ctx->counters, &ctx->out_pairs, &ctx->small_out, &ctx->hist_tmp, &ctx->scan_tmp, &ctx->hist2,
-                     &ctx->grp_rng, &ctx->unit_start2, &ctx->narrow_flag};
+                     &ctx->grp_rng, &ctx->unit_start2, &ctx->narrow_flag, &ctx->seg_rng, &ctx->tag_base,
+                     &ctx->shard_ps[0], &ctx->shard_ps[1], &ctx->shard_mm};
     for (DevBuf *b : all) release(*b);
     ctx->small_hdr_clean = false;
     for (auto &b : ctx->free_blocks) {
@@ -748,7 +842,7 @@ int rhj_set_option(rhj_ctx *ctx, const char *name, int64_t value)
     }
     if (n == "partition.narrow" && value >= -1 && value <= 2) {
         ctx->opt_narrow = (int)value;
-        if (value != 0) ctx->narrow_gave_up = false;
+        ctx->narrow_fail_streak = ctx->narrow_skip = 0;
         return RHJ_OK;
     }
     return fail(ctx, RHJ_E_INVALID, "rhj_set_option: unknown option or value: " + n);
@@ -887,9 +981,17 @@ int join_small_host(rhj_ctx *ctx, const rhj_tuple *R, u64 nR, const rhj_tuple *S
     const u64 guess = (nR > nS ? nR : nS) + 1024, landcap = LAND_BYTES / 16;
     RHJCHK(ensure(ctx, ctx->in_R, (size_t)nR * 16));
     RHJCHK(ensure(ctx, ctx->in_S, (size_t)nS * 16));
-    if (!ctx->h_land) {
+    if (!ctx->h_land || !ctx->h_land_dev) {
+        if (ctx->h_land) { (void)hipHostFree(ctx->h_land); ctx->h_land = nullptr; }      // an earlier attempt got the memory but no device address
+        ctx->h_land_dev = nullptr;
         HIPCHK(ctx, hipHostMalloc((void **)&ctx->h_land, 64 + LAND_BYTES, hipHostMallocDefault));
-        HIPCHK(ctx, hipHostGetDevicePointer((void **)&ctx->h_land_dev, ctx->h_land, 0));
+        const hipError_t e = hipHostGetDevicePointer((void **)&ctx->h_land_dev, ctx->h_land, 0);
+        if (e != hipSuccess || !ctx->h_land_dev) {
+            (void)hipHostFree(ctx->h_land);
+            ctx->h_land = nullptr;
+            ctx->h_land_dev = nullptr;
+            return fail(ctx, RHJ_E_HIP, std::string("hipHostGetDevicePointer: ") + hipGetErrorString(e));
+        }
     }
     if (ctx->small_out.cap < 64 + (size_t)guess * 16) {
         RHJCHK(ensure(ctx, ctx->small_out, 64 + (size_t)guess * 16));
@@ -898,8 +1000,14 @@ int join_small_host(rhj_ctx *ctx, const rhj_tuple *R, u64 nR, const rhj_tuple *S
     HIPCHK(ctx, hipMemcpyAsync(ctx->in_R.p, R, (size_t)nR * 16, hipMemcpyHostToDevice, ctx->stream));
     HIPCHK(ctx, hipMemcpyAsync(ctx->in_S.p, S, (size_t)nS * 16, hipMemcpyHostToDevice, ctx->stream));
     ctx->last.passes = 0;
+    ctx->last.bits1 = ctx->last.bits2 = 0;
+    ctx->last.ntasks = 0;
+    ctx->last_join_kind = -1;
+    ctx->cur_narrow = 0;
     u64 count = 0, landed = 0;
+    const u64 unpublished = ~0ull;                                            // the kernel's last workgroup overwrites it with the count
     for (int attempt = 0; attempt < 2; attempt++) {
+        *(volatile u64 *)ctx->h_land = unpublished;
         // device buffer: {64-byte header: [0] count, [8] finished workgroups | pairs}; the first MiB of pairs and the count
         // land in pinned host memory as well, written by the kernel itself
         unsigned char *d_hdr = (unsigned char *)ctx->small_out.p;
@@ -916,6 +1024,7 @@ int join_small_host(rhj_ctx *ctx, const rhj_tuple *R, u64 nR, const rhj_tuple *S
         HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
         ctx->small_hdr_clean = true;                                      // the last workgroup zeroed the counters
         count = *(volatile const u64 *)ctx->h_land;
+        if (count == unpublished) return fail(ctx, RHJ_E_HIP, "the direct join kernel did not publish its result count");
         landed = dcap < landcap ? dcap : landcap;
         if (trace) fprintf(stderr, "[small join %llu x %llu -> %llu] enqueue %.1f  sync %.1f us\n", (unsigned long long)nR,
                            (unsigned long long)nS, (unsigned long long)count, us(t0, t1), us(t1, now()));
@@ -1086,14 +1195,201 @@ int rhj_bucket_join(rhj_ctx *ctx, const rhj_tuple *d_Rp, const uint64_t *d_start
         return fail(ctx, RHJ_E_INVALID, "bad rhj_bucket_join argument");
     prof_reset(ctx);
     // sizes are the last boundary of each side
-    u64 ends[2] = {0, 0};
+    u64 ends[2] = {0, 0}, begs[2] = {0, 0};
     HIPCHK(ctx, hipMemcpyAsync(&ends[0], d_startR + nparts, 8, hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(ctx, hipMemcpyAsync(&ends[1], d_startS + nparts, 8, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipMemcpyAsync(&begs[0], d_startR, 8, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipMemcpyAsync(&begs[1], d_startS, 8, hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     *out_count = 0;
-    if (ends[0] == 0 || ends[1] == 0) return RHJ_OK;
+    if (ends[0] <= begs[0] || ends[1] <= begs[1]) return RHJ_OK;
+    // the one-launch small-join path assumes boundaries {0, n}; the compact-table kernel trusts radix_bits: checked on the device
     RHJCHK(join_phase_on(ctx, d_Rp, (const u64 *)d_startR, ends[0], d_Sp, (const u64 *)d_startS, ends[1], nparts,
-                         radix_bits, (u32)probe_split, d_out, out_capacity, (u64 *)out_count));
+                         radix_bits, (u32)probe_split, d_out, out_capacity, (u64 *)out_count, false, nullptr,
+                         begs[0] == 0 && begs[1] == 0, true));
+    if (d_out && *out_count > out_capacity) return fail(ctx, RHJ_E_OVERFLOW, "result buffer too small");
+    return RHJ_OK;
+}
+
+
+// ---- multi-GPU stage entry points ---------------------------------------------------------------------
+// Sender: class histogram (+ rowID range) of a shard, then the class split into the narrow wire format; receiver: the fused
+// two-pass partition of what arrived (sender segments -> sender tags) and the bucket join that resolves the tags.
+namespace {
+
+struct ShardTables { DevBuf *seg0, *unit_start, *unit_hist, *unit_base, *scan_tmp; };
+
+ShardTables shard_tables(rhj_ctx *ctx, int side)
+{
+    if (side == 0) return {&ctx->seg0, &ctx->unit_start, &ctx->unit_hist, &ctx->unit_base, &ctx->scan_tmp};
+    return {&ctx->seg0_b, &ctx->unit_start_b, &ctx->unit_hist_b, &ctx->unit_base_b, &ctx->scan_tmp_b};
+}
+
+}  // namespace
+
+uint64_t rhj_narrow_key_offset(uint64_t n) { return narrow_k_offset(n); }
+uint64_t rhj_narrow_bytes(uint64_t n) { return (narrow_k_offset(n) + n * 4 + 255) & ~(uint64_t)255; }
+
+int rhj_shard_plan(uint64_t nR, uint64_t nS, const rhj_opts *in, rhj_opts *resolved)
+{
+    if (!resolved) return RHJ_E_INVALID;
+    rhj_opts o;
+    if (resolve_plan(nR, nS, in, &o, true) != RHJ_OK) return RHJ_E_INVALID;
+    *resolved = o;
+    if (o.passes != 2 || !fused_two_pass_ok(o.bits1, o.bits2) || !narrow_pass_ok(o.bits1) || !narrow_pass_ok(o.bits2)) return 0;
+    if (o.bits1 < tag_bits() || nR < NARROW_MIN_TUPLES || nS < NARROW_MIN_TUPLES || nR >= ((u64)1 << 32) || nS >= ((u64)1 << 32)) return 0;
+    rhj_ctx probe;                                      // default options: which kernel would join partitions of this size
+    const int tb = o.bits1 + o.bits2;
+    const int kind = choose_join_kind(&probe, nR, nS, (u64)1 << tb, tb);
+    return (kind == JK_CT || kind == JK_CT_HALF || kind == JK_BKT) ? 1 : 0;
+}
+
+int rhj_shard_stats(rhj_ctx *ctx, int side, const rhj_tuple *d_rel, uint64_t n, int shift, int bits, uint64_t *hist,
+                    uint64_t *key_min, uint64_t *key_max)
+{
+    RHJCHK(use_device(ctx));
+    if ((side != 0 && side != 1) || bits < 1 || bits > 8 || shift < 0 || shift + bits > 64 || !hist || (n && !d_rel))
+        return fail(ctx, RHJ_E_INVALID, "bad rhj_shard_stats argument");
+    prof_reset(ctx);
+    const size_t nbins = (size_t)1 << bits;
+    const ShardTables t = shard_tables(ctx, side);
+    const PassGeom g = make_geom(n, 1, shift, bits);
+    RHJCHK(ensure(ctx, *t.seg0, 64));
+    RHJCHK(ensure(ctx, *t.unit_start, 16));
+    RHJCHK(ensure(ctx, *t.unit_hist, (size_t)g.max_units * nbins * 4));
+    RHJCHK(ensure(ctx, *t.unit_base, (size_t)g.max_units * nbins * 8));
+    RHJCHK(ensure(ctx, *t.scan_tmp, scan_tmp_bytes(bits)));
+    RHJCHK(ensure(ctx, ctx->shard_ps[side], (nbins + 1) * 8));
+    RHJCHK(ensure(ctx, ctx->shard_mm, 64));
+    u64 *mm = (u64 *)ctx->shard_mm.p + 2 * side;
+    const u64 init[2] = {~0ull, 0ull};
+    {
+        Span s(ctx, RHJ_K_AUX);
+        HIPCHK(ctx, hipMemcpyAsync(mm, init, 16, hipMemcpyHostToDevice, ctx->stream));
+        launch_init_single_segment(ctx->stream, n, g.L, (u64 *)t.seg0->p, (u32 *)t.unit_start->p);
+    }
+    {
+        Span s(ctx, RHJ_K_HIST);
+        launch_hist_units(ctx->stream, d_rel, g, (const u64 *)t.seg0->p, (const u32 *)t.unit_start->p, (u32 *)t.unit_hist->p, mm);
+    }
+    {
+        Span s(ctx, RHJ_K_SCAN);
+        launch_scan_units(ctx->stream, g, (const u64 *)t.seg0->p, (const u32 *)t.unit_start->p, (const u32 *)t.unit_hist->p,
+                          (u64 *)t.unit_base->p, (u64 *)ctx->shard_ps[side].p, (u64 *)t.scan_tmp->p);
+    }
+    RHJCHK(check_launch(ctx, "rhj_shard_stats"));
+    std::vector<u64> ps(nbins + 1);
+    u64 hmm[2] = {0, 0};
+    HIPCHK(ctx, hipMemcpyAsync(ps.data(), ctx->shard_ps[side].p, (nbins + 1) * 8, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipMemcpyAsync(hmm, mm, 16, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    for (size_t b = 0; b < nbins; b++) hist[b] = n ? ps[b + 1] - ps[b] : 0;
+    if (key_min) *key_min = n ? hmm[0] : 0;
+    if (key_max) *key_max = n ? hmm[1] : 0;
+    ctx->shard_n[side] = n;
+    ctx->shard_kmin[side] = n ? hmm[0] : 0;
+    ctx->shard_kmax[side] = n ? hmm[1] : 0;
+    return RHJ_OK;
+}
+
+int rhj_shard_split(rhj_ctx *ctx, int side, const rhj_tuple *d_rel, uint64_t n, int shift, int bits, uint64_t key_base,
+                    void *d_narrow_out, uint64_t *d_class_start)
+{
+    RHJCHK(use_device(ctx));
+    if ((side != 0 && side != 1) || bits < 1 || bits > 8 || shift < 0 || shift + bits > 64 || !d_narrow_out || (n && !d_rel))
+        return fail(ctx, RHJ_E_INVALID, "bad rhj_shard_split argument");
+    if (ctx->shard_n[side] != n || !ctx->shard_ps[side].p)
+        return fail(ctx, RHJ_E_INVALID, "rhj_shard_split: call rhj_shard_stats for this side and relation first");
+    if (n && (key_base > ctx->shard_kmin[side] || ctx->shard_kmax[side] - key_base >= ((u64)1 << 32)))
+        return fail(ctx, RHJ_E_INVALID, "rhj_shard_split: rowID - key_base must lie in [0, 2^32) for every tuple of the shard "
+                                        "(rhj_shard_stats reports the range)");
+    prof_reset(ctx);
+    const size_t nbins = (size_t)1 << bits;
+    const ShardTables t = shard_tables(ctx, side);
+    const PassGeom g = make_geom(n, 1, shift, bits);
+    RHJCHK(ensure(ctx, ctx->narrow_flag, 64));
+    {
+        Span s(ctx, RHJ_K_AUX);
+        HIPCHK(ctx, hipMemsetAsync(ctx->narrow_flag.p, 0, 64, ctx->stream));
+    }
+    {
+        Span s(ctx, RHJ_K_SCATTER);
+        launch_scatter_units_narrow(ctx->stream, d_rel, d_narrow_out, n, g, (const u64 *)t.seg0->p, (const u32 *)t.unit_start->p,
+                                    (const u64 *)t.unit_base->p, (u32 *)ctx->narrow_flag.p, key_base);
+    }
+    if (d_class_start)
+        HIPCHK(ctx, hipMemcpyAsync(d_class_start, ctx->shard_ps[side].p, (nbins + 1) * 8, hipMemcpyDeviceToDevice, ctx->stream));
+    return check_launch(ctx, "rhj_shard_split");
+}
+
+int rhj_shard_partition(rhj_ctx *ctx, int side, const uint64_t *d_payloads, const uint32_t *d_rowids, uint64_t m, int nseg,
+                        const uint64_t *seg_off, const rhj_opts *plan)
+{
+    RHJCHK(use_device(ctx));
+    if ((side != 0 && side != 1) || !plan || plan->passes != 2 || !seg_off || nseg < 1 || nseg > seg_max() || seg_off[0] != 0 ||
+        seg_off[nseg] != m || (m && (!d_payloads || !d_rowids)))
+        return fail(ctx, RHJ_E_INVALID, "bad rhj_shard_partition argument");
+    if (!fused_two_pass_ok(plan->bits1, plan->bits2) || !narrow_pass_ok(plan->bits1) || !narrow_pass_ok(plan->bits2) ||
+        plan->bits1 < tag_bits() || m >= ((u64)1 << 32))
+        return fail(ctx, RHJ_E_INVALID, "rhj_shard_partition: not a plan of the narrow format (see rhj_shard_plan)");
+    for (int i = 0; i < nseg; i++)
+        if (seg_off[i] > seg_off[i + 1]) return fail(ctx, RHJ_E_INVALID, "rhj_shard_partition: segment offsets must not decrease");
+    prof_reset(ctx);
+    const int tb = plan->bits1 + plan->bits2;
+    const size_t np = (size_t)1 << tb;
+    DevBuf &part = side == 0 ? ctx->part_R : ctx->part_S;
+    DevBuf &ps = side == 0 ? ctx->ps_R : ctx->ps_S;
+    RHJCHK(ensure(ctx, part, (size_t)(m ? m : 1) * 16));
+    RHJCHK(ensure(ctx, ps, (np + 1) * 8));
+    RHJCHK(ensure(ctx, ctx->narrow_flag, 64));
+    {
+        Span s(ctx, RHJ_K_AUX);
+        HIPCHK(ctx, hipMemsetAsync(ctx->narrow_flag.p, 0, 64, ctx->stream));
+    }
+    ctx->counters_clean = false;
+    if (m == 0) {                                       // nothing arrived: all boundaries 0
+        HIPCHK(ctx, hipMemsetAsync(ps.p, 0, (np + 1) * 8, ctx->stream));
+    } else {
+        FusedIn in;
+        in.P = (const u64 *)d_payloads;
+        in.K = (const u32 *)d_rowids;
+        in.nseg = nseg;
+        in.seg_off = (const u64 *)seg_off;
+        RHJCHK(partition_relation_fused(ctx, in, m, plan->bits1, plan->bits2, part.p, (u64 *)ps.p, 2));
+    }
+    ctx->shard_side_done[side] = true;
+    ctx->shard_n[side] = m;
+    ctx->shard_nseg = nseg;
+    ctx->shard_plan = *plan;
+    return RHJ_OK;
+}
+
+int rhj_shard_join(rhj_ctx *ctx, int nseg, const uint64_t *row0_R, const uint64_t *row0_S, rhj_pair *d_out, uint64_t out_capacity,
+                   uint64_t *out_count)
+{
+    RHJCHK(use_device(ctx));
+    if (!out_count || !row0_R || !row0_S || nseg < 1 || nseg > seg_max())
+        return fail(ctx, RHJ_E_INVALID, "bad rhj_shard_join argument");
+    if (!ctx->shard_side_done[0] || !ctx->shard_side_done[1] || ctx->shard_nseg != nseg)
+        return fail(ctx, RHJ_E_INVALID, "rhj_shard_join: rhj_shard_partition both sides (0 and 1) with the same segment count first");
+    *out_count = 0;
+    prof_reset(ctx);
+    const u64 mR = ctx->shard_n[0], mS = ctx->shard_n[1];
+    if (mR == 0 || mS == 0) return RHJ_OK;
+    u64 bases[32] = {0};
+    for (int i = 0; i < nseg; i++) { bases[i] = row0_R[i]; bases[16 + i] = row0_S[i]; }
+    RHJCHK(ensure(ctx, ctx->tag_base, sizeof(bases)));
+    HIPCHK(ctx, hipMemcpyAsync(ctx->tag_base.p, bases, sizeof(bases), hipMemcpyHostToDevice, ctx->stream));   // (pageable source: staged before the call returns)
+    const int tb = ctx->shard_plan.bits1 + ctx->shard_plan.bits2;
+    ctx->cur_narrow = 2;
+    ctx->last.passes = 2;
+    ctx->last.bits1 = ctx->shard_plan.bits1;
+    ctx->last.bits2 = ctx->shard_plan.bits2;
+    int rc = join_phase_on(ctx, ctx->part_R.p, (const u64 *)ctx->ps_R.p, mR, ctx->part_S.p, (const u64 *)ctx->ps_S.p, mS,
+                           (u64)1 << tb, tb, (u32)ctx->shard_plan.probe_split, d_out, d_out ? out_capacity : 0, (u64 *)out_count, true,
+                           (const u64 *)ctx->tag_base.p, false);
+    if (rc == RHJ_RETRY_WIDE) return fail(ctx, RHJ_E_HIP, "rhj_shard_join: unexpected wide-rowID flag");
+    RHJCHK(rc);
     if (d_out && *out_count > out_capacity) return fail(ctx, RHJ_E_OVERFLOW, "result buffer too small");
     return RHJ_OK;
 }

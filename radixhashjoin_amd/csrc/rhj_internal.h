@@ -52,19 +52,23 @@ struct PassGeom {
 // launchers (all asynchronous on `st`)
 void launch_init_single_segment(hipStream_t st, u64 n, u64 L, u64 *d_seg_start, u32 *d_unit_start);
 void launch_make_units(hipStream_t st, const u64 *d_seg_start, u32 nseg, u64 L, u32 *d_unit_start);
+// d_minmax (may be null): two u64, atomicMin / atomicMax of the rowIDs seen
 void launch_hist_units(hipStream_t st, const void *d_in, const PassGeom &g, const u64 *d_seg_start,
-                       const u32 *d_unit_start, u32 *d_unit_hist);
+                       const u32 *d_unit_start, u32 *d_unit_hist, u64 *d_minmax = nullptr);
 void launch_scan_units(hipStream_t st, const PassGeom &g, const u64 *d_seg_start, const u32 *d_unit_start,
                        const u32 *d_unit_hist, u64 *d_unit_base, u64 *d_part_start, u64 *d_scan_tmp);
 void launch_scatter_units(hipStream_t st, const void *d_in, void *d_out, const PassGeom &g,
                           const u64 *d_seg_start, const u32 *d_unit_start, const u64 *d_unit_base);
 void launch_diff_hist(hipStream_t st, const u64 *d_start, u64 nbins, u64 *d_hist);
+void launch_check_radix(hipStream_t st, const void *d_R, const u64 *d_startR, const void *d_S, const u64 *d_startS, u64 nparts,
+                        int radix_bits, u64 *d_bad);
 void launch_prefix(hipStream_t st, const u64 *d_hist, u64 nbins, u64 *d_start);
 void launch_make_tasks(hipStream_t st, const u64 *d_startR, const u64 *d_startS, u64 nparts, u32 probe_split,
                        JoinTask *d_tasks, u32 *d_ntasks, u32 max_tasks, u64 *d_stats, int kind);
 void launch_join(hipStream_t st, const void *d_R, const u64 *d_startR, const void *d_S, const u64 *d_startS,
                  const JoinTask *d_tasks, const u32 *d_ntasks, u32 grid, int radix_bits,
-                 void *d_out, u64 out_capacity, u64 *d_out_count, int kind, const u32 *d_RK = nullptr, const u32 *d_SK = nullptr);
+                 void *d_out, u64 out_capacity, u64 *d_out_count, int kind, const u32 *d_RK = nullptr, const u32 *d_SK = nullptr,
+                 const u64 *d_tag_base = nullptr, const u32 *d_skip = nullptr);
 void launch_join_direct(hipStream_t st, const void *d_R, u64 nR, const void *d_S, u64 nS, void *d_out, u64 out_capacity,
                         u64 *d_out_count, u64 *host_count = nullptr, u32 *d_done = nullptr, void *host_out = nullptr,
                         u64 host_cap = 0);
@@ -94,8 +98,15 @@ enum JoinKernel { JK_BKT = 0, JK_BKT_BIG = 1, JK_CT = 2, JK_CT_HALF = 3 };
 u32 join_probe_split(int kind);      // probe tuples per task the kernel holds at most (0: no limit of its own)
 u32 join_table_tuples(int kind);     // build tuples per LDS table
 int join_ct_min_radix_bits();
-void launch_hist2d_units(hipStream_t st, const void *d_in, u64 n, u64 L, u32 units, int b1, int b2,
-                         u32 units_per_group, u32 ngroups, u32 *d_hist1, u32 *d_hist2);
+// in_narrow: d_in is a payload array (u64).  key_base / d_wide (16-byte input): d_wide (may be null) is OR-ed with 1 when some
+// rowID - key_base does not fit 32 bits.  d_unit_rng (may be null): explicit pass-1 units (launch_seg_units).
+void launch_hist2d_units(hipStream_t st, const void *d_in, bool in_narrow, u64 n, u64 L, u32 units, int b1, int b2,
+                         u32 units_per_group, u32 ngroups, u32 *d_hist1, u32 *d_hist2, u64 key_base, u32 *d_wide,
+                         const u64 *d_unit_rng);
+void launch_seg_units(hipStream_t st, u32 nseg, const u64 *seg_off, const u64 *seg_L, u32 units_per_seg, u64 *d_unit_rng,
+                      u64 *d_seg_start, u32 *d_unit_start);
+int seg_max();                                             // segments (= ranks) a receiver can tell apart: 16
+int tag_bits();                                            // low payload bits that carry the sender number at the receiver
 void launch_make_group_ranges(hipStream_t st, const u64 *d_unit_base1, u32 nb1, u32 units_per_group, u32 ngroups, u64 n,
                               u64 *d_rng, u32 *d_unit_start2);
 void launch_scatter_ranges(hipStream_t st, const void *d_in, void *d_out, u32 nunits, int shift, int bits,
@@ -108,8 +119,11 @@ constexpr u64 NARROW_AUTO_MIN_TUPLES = 8000000;         // automatic choice: lar
                                                         // either way; 16M ... 256M: 5-8 % faster narrow; 10^9: 19 %)
 bool narrow_pass_ok(int bits);
 void launch_scatter_units_narrow(hipStream_t st, const void *d_in, void *d_out, u64 n, const PassGeom &g,
-                                 const u64 *d_seg_start, const u32 *d_unit_start, const u64 *d_unit_base, u32 *d_overflow);
+                                 const u64 *d_seg_start, const u32 *d_unit_start, const u64 *d_unit_base, u32 *d_overflow,
+                                 u64 key_base = 0);
 void launch_scatter_ranges_narrow(hipStream_t st, const void *d_in, bool in_narrow, void *d_out, u64 n, u32 nunits, int shift,
-                                  int bits, const u64 *d_unit_base, const u64 *d_rng, u32 *d_overflow);
+                                  int bits, const u64 *d_unit_base, const u64 *d_rng, u32 *d_overflow, u32 tag_groups = 0,
+                                  u32 tag_div = 0, const u32 *d_inK = nullptr);   // d_inK: narrow input whose rowID array is not at narrow_k_offset(n)
+const char *launch_attr_error();                       // text of the first refused hipFuncSetAttribute, or null
 size_t scan_tmp_bytes(int bits);
 size_t part_lds_bytes(int bits);

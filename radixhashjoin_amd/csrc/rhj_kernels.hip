@@ -21,6 +21,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <mutex>
+#include <string>
 #include <type_traits>
 #include <vector>
 
@@ -102,6 +103,28 @@ __global__ void k_init_single_segment(u64 n, u64 L, u64 *seg_start, u32 *unit_st
     }
 }
 
+// Pass-1 units of a relation that arrived in SEGMENTS (multi-GPU receiver: segment s = the tuples sender s sent): every
+// segment is cut into the same number of units (units past a short segment's end are empty), so unit u belongs to segment
+// u / units_per_seg and no unit straddles two senders.  Also writes the one-segment tables {0, n}, {0, units}.
+constexpr int SEG_MAX = 16;
+struct SegPlan { u32 nseg, units_per_seg; u64 off[SEG_MAX + 1]; u64 L[SEG_MAX]; };
+
+__global__ void __launch_bounds__(256) k_seg_units(SegPlan sp, u64 *__restrict__ unit_rng, u64 *__restrict__ seg_start,
+                                                   u32 *__restrict__ unit_start)
+{
+    const u32 total = sp.nseg * sp.units_per_seg;
+    for (u32 u = blockIdx.x * 256 + threadIdx.x; u <= total; u += gridDim.x * 256) {
+        if (u == total) { unit_rng[u] = sp.off[sp.nseg]; continue; }
+        const u32 s = u / sp.units_per_seg, j = u % sp.units_per_seg;
+        const u64 b = sp.off[s] + (u64)j * sp.L[s];
+        unit_rng[u] = b < sp.off[s + 1] ? b : sp.off[s + 1];
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        seg_start[0] = 0; seg_start[1] = sp.off[sp.nseg];
+        unit_start[0] = 0; unit_start[1] = total;
+    }
+}
+
 // ---- both relations of a join through the same launches (one-pass plans: mid-size joins are launch-bound) -----------
 // blockIdx.y selects the relation; the kernels below are the single-relation bodies called with that relation's arguments.
 struct PassRel {                      // one relation's side of a partition pass
@@ -159,7 +182,7 @@ __global__ void __launch_bounds__(1024) k_make_units(const u64 *__restrict__ seg
 // ------------------------------------------------------------------------------------------------
 __device__ __forceinline__ void
 dev_hist_units(const Tup *__restrict__ in, const u64 *__restrict__ seg_start, const u32 *__restrict__ unit_start,
-               u32 nseg, u64 L, int shift, int bits, u32 *__restrict__ unit_hist, const u32 u)
+               u32 nseg, u64 L, int shift, int bits, u32 *__restrict__ unit_hist, const u32 u, u64 *__restrict__ minmax = nullptr)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     u32 *cnt = reinterpret_cast<u32 *>(smem);
@@ -174,6 +197,7 @@ dev_hist_units(const Tup *__restrict__ in, const u64 *__restrict__ seg_start, co
     __syncthreads();
 
     u64 i = beg + threadIdx.x;
+    u64 kmin = ~0ull, kmax = 0;                        // range of the rowIDs (minmax != nullptr: the multi-GPU sender's class histogram)
     // 4 independent 16 B loads in flight per lane
     for (; i + 3ull * PART_THREADS < end; i += 4ull * PART_THREADS) {
         const Tup t0 = in[i], t1 = in[i + PART_THREADS], t2 = in[i + 2 * PART_THREADS], t3 = in[i + 3 * PART_THREADS];
@@ -181,8 +205,29 @@ dev_hist_units(const Tup *__restrict__ in, const u64 *__restrict__ seg_start, co
         atomicAdd(&cnt[(u32)(t1.payload >> shift) & mask], 1u);
         atomicAdd(&cnt[(u32)(t2.payload >> shift) & mask], 1u);
         atomicAdd(&cnt[(u32)(t3.payload >> shift) & mask], 1u);
+        if (minmax != nullptr) {
+            const u64 a = t0.key < t1.key ? t0.key : t1.key, b = t2.key < t3.key ? t2.key : t3.key;
+            const u64 c = t0.key > t1.key ? t0.key : t1.key, d = t2.key > t3.key ? t2.key : t3.key;
+            const u64 lo = a < b ? a : b, hi = c > d ? c : d;
+            kmin = lo < kmin ? lo : kmin;
+            kmax = hi > kmax ? hi : kmax;
+        }
     }
-    for (; i < end; i += PART_THREADS) atomicAdd(&cnt[(u32)(in[i].payload >> shift) & mask], 1u);
+    for (; i < end; i += PART_THREADS) {
+        const Tup t = in[i];
+        atomicAdd(&cnt[(u32)(t.payload >> shift) & mask], 1u);
+        kmin = t.key < kmin ? t.key : kmin;
+        kmax = t.key > kmax ? t.key : kmax;
+    }
+    if (minmax != nullptr) {
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+            const u64 a = __shfl_down(kmin, off, 64), b = __shfl_down(kmax, off, 64);
+            kmin = a < kmin ? a : kmin;
+            kmax = b > kmax ? b : kmax;
+        }
+        if ((threadIdx.x & 63) == 0 && beg < end) { atomicMin(&minmax[0], kmin); atomicMax(&minmax[1], kmax); }
+    }
     __syncthreads();
     u32 *out = unit_hist + (u64)u * nbins;
     for (u32 b = threadIdx.x; b < nbins; b += PART_THREADS) out[b] = cnt[b];
@@ -190,9 +235,9 @@ dev_hist_units(const Tup *__restrict__ in, const u64 *__restrict__ seg_start, co
 
 __global__ void __launch_bounds__(PART_THREADS)
 k_hist_units(const Tup *__restrict__ in, const u64 *__restrict__ seg_start, const u32 *__restrict__ unit_start,
-             u32 nseg, u64 L, int shift, int bits, u32 *__restrict__ unit_hist)
+             u32 nseg, u64 L, int shift, int bits, u32 *__restrict__ unit_hist, u64 *__restrict__ minmax)
 {
-    dev_hist_units(in, seg_start, unit_start, nseg, L, shift, bits, unit_hist, blockIdx.x);
+    dev_hist_units(in, seg_start, unit_start, nseg, L, shift, bits, unit_hist, blockIdx.x, minmax);
 }
 
 __global__ void __launch_bounds__(PART_THREADS) k_hist_units2(PassPair a, int shift, int bits)
@@ -216,18 +261,29 @@ __global__ void __launch_bounds__(PART_THREADS) k_hist_units2(PassPair a, int sh
 // ------------------------------------------------------------------------------------------------
 constexpr int H2_THREADS = 1024;
 
+// unit_rng (optional): explicit pass-1 units, unit u = rows [unit_rng[u], unit_rng[u+1]) (the multi-GPU receiver cuts its
+// pass-1 units at the sender segments of the receive buffer -- k_seg_units -- so that a group of pass-1 units, hence a
+// pass-2 unit, holds tuples of ONE sender).  Null: unit u = rows [u * L, (u+1) * L).  Group = u / units_per_group either way.
+
+// IN_NARROW: the input is a payload array (8 B/tuple; a received narrow shard), no rowIDs to inspect.
+template <bool IN_NARROW>
 __global__ void __launch_bounds__(H2_THREADS)
-k_hist2d_units(const Tup *__restrict__ in, u64 n, u64 L, int b1, int b2, u32 units_per_group, u32 ngroups,
-               u32 *__restrict__ hist1, u32 *__restrict__ hist2)
+k_hist2d_units(const Tup *__restrict__ in, const u64 *__restrict__ inP, u64 n, u64 L, int b1, int b2, u32 units_per_group,
+               u32 ngroups, u32 *__restrict__ hist1, u32 *__restrict__ hist2, u64 key_base, u32 *__restrict__ wide,
+               const u64 *__restrict__ unit_rng)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const u32 nb1 = 1u << b1, nb2 = 1u << b2, nbin = nb1 * nb2;
     u32 *tab = reinterpret_cast<u32 *>(smem);                 // nbin / 2 words, two 16-bit counters each
     u32 *sum1 = tab + (nbin >> 1);                            // nb1
     const u32 u = blockIdx.x;
-    const u64 beg = (u64)u * L;
-    if (beg >= n) return;
-    const u64 end = (beg + L < n) ? beg + L : n;
+    u64 beg, end;
+    if (unit_rng != nullptr) { beg = unit_rng[u]; end = unit_rng[u + 1]; }
+    else {
+        beg = (u64)u * L;
+        if (beg >= n) return;
+        end = (beg + L < n) ? beg + L : n;
+    }
     const u32 grp = u / units_per_group;
     const int tid = threadIdx.x, lane = tid & 63;
     const u32 m1 = nb1 - 1, m2 = nb2 - 1;
@@ -246,11 +302,28 @@ k_hist2d_units(const Tup *__restrict__ in, u64 n, u64 L, int b1, int b2, u32 uni
         }
     };
     u64 i = beg + tid;
-    for (; i + 3ull * H2_THREADS < end; i += 4ull * H2_THREADS) {
-        const Tup t0 = in[i], t1 = in[i + H2_THREADS], t2 = in[i + 2 * H2_THREADS], t3 = in[i + 3 * H2_THREADS];
-        count(t0.payload); count(t1.payload); count(t2.payload); count(t3.payload);
+    if constexpr (IN_NARROW) {
+        for (; i + 7ull * H2_THREADS < end; i += 8ull * H2_THREADS) {        // 8 x 8 B loads in flight per lane
+            u64 v[8];
+#pragma unroll
+            for (int k = 0; k < 8; k++) v[k] = inP[i + (u64)k * H2_THREADS];
+#pragma unroll
+            for (int k = 0; k < 8; k++) count(v[k]);
+        }
+        for (; i < end; i += H2_THREADS) count(inP[i]);
+    } else {
+        // wide (optional): the narrow format is wanted downstream -- this kernel sees every rowID anyway, so a rowID that
+        // does not fit 32 bits (after subtracting key_base) is reported here, before any scatter has run
+        u32 hi = 0;
+        for (; i + 3ull * H2_THREADS < end; i += 4ull * H2_THREADS) {
+            const Tup t0 = in[i], t1 = in[i + H2_THREADS], t2 = in[i + 2 * H2_THREADS], t3 = in[i + 3 * H2_THREADS];
+            count(t0.payload); count(t1.payload); count(t2.payload); count(t3.payload);
+            hi |= (u32)((t0.key - key_base) >> 32) | (u32)((t1.key - key_base) >> 32) | (u32)((t2.key - key_base) >> 32) |
+                  (u32)((t3.key - key_base) >> 32);
+        }
+        for (; i < end; i += H2_THREADS) { const Tup t = in[i]; count(t.payload); hi |= (u32)((t.key - key_base) >> 32); }
+        if (wide != nullptr && __ballot(hi != 0) != 0 && lane == 0) atomicOr(wide, 1u);
     }
-    for (; i < end; i += H2_THREADS) count(in[i].payload);
     __syncthreads();
 
     // flush: 64 consecutive bins per wavefront instruction (one 256 B row segment of hist2 when nb2 >= 64)
@@ -812,14 +885,26 @@ __global__ void __launch_bounds__(THREADS) k_scatter_wc2(PassPair a, int shift, 
 // ------------------------------------------------------------------------------------------------
 constexpr int WN_THREADS = 1024, WN_TPT = 4, WN_GR = 32, WN_MAX_BITS = 8;
 
+// key_base (16-byte input): the rowID stored is key - key_base (a shard of a range-sharded relation sends rowIDs local to
+//   the shard; the receiver adds the sender's base again in the join, see WnTag).
+// tag (explicit unit ranges only): unit u carries tuples of ONE sender (the multi-GPU receiver cuts its pass-1 units at the
+//   sender segments of the receive buffer, so group g = u % tag.ngroups of pass-1 units belongs to sender g / tag.div); the
+//   low tag.bits bits of a payload -- constant inside the partition from here on, hence dead -- are replaced by that
+//   sender number, which the join kernels turn back into a global rowID (row0[sender] + local rowID).
+struct WnTag { u32 ngroups, div, bits; };   // bits == 0: no tagging
+constexpr u32 TAG_BITS = 4, TAG_MAX = 1u << TAG_BITS;   // sender tags in the low payload bits: <= 16 ranks (== SEG_MAX)
+
 template <bool IN_NARROW>
 __global__ void __launch_bounds__(WN_THREADS)
 k_scatter_wcn(const Tup *__restrict__ in, const u64 *__restrict__ inP, const u32 *__restrict__ inK,
               u64 *__restrict__ outP, u32 *__restrict__ outK, const u64 *__restrict__ seg_start,
               const u32 *__restrict__ unit_start, u32 nseg, u64 L, int shift, int bits,
               const u64 *__restrict__ unit_base, const u64 *__restrict__ unit_rng, u32 n_rng_units,
-              u32 *__restrict__ overflow)
+              u32 *__restrict__ overflow, u64 key_base, WnTag tag)
 {
+    // a rowID that does not fit 32 bits has been seen (by the histogram kernel or by an earlier workgroup of this pass):
+    // the join is going to repeat itself in the 16-byte format, nothing written from here on will be read
+    if (overflow != nullptr && __builtin_nontemporal_load(overflow) != 0) return;
     constexpr int THREADS = WN_THREADS, TPT = WN_TPT, TILE = THREADS * TPT, GR = WN_GR;
     constexpr u64 GM = GR - 1;
     using KeyT = typename std::conditional<IN_NARROW, u32, u64>::type;
@@ -851,6 +936,8 @@ k_scatter_wcn(const Tup *__restrict__ in, const u64 *__restrict__ inP, const u32
         end = (beg + L < send) ? beg + L : send;
     }
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const u64 tag_keep = ~(((u64)1 << tag.bits) - 1);                        // tag.bits == 0: keeps every bit
+    const u64 tag_or = tag.bits ? (u64)((u % tag.ngroups) / tag.div) : 0ull;
 
     for (u32 b = tid; b < nbins; b += THREADS) {
         const u64 g = unit_base[(u64)u * nbins + b];
@@ -867,7 +954,7 @@ k_scatter_wcn(const Tup *__restrict__ in, const u64 *__restrict__ inP, const u32
         for (int k = 0; k < TPT; k++) {                                      // unconditional loads (see dev_scatter_wc)
             const u32 i0 = k * THREADS + tid, i = i0 < last ? i0 : last;
             if constexpr (IN_NARROW) { pay[k] = inP[tb + i]; key[k] = inK[tb + i]; }
-            else { const Tup v = in[tb + i]; pay[k] = v.payload; key[k] = v.key; }
+            else { const Tup v = in[tb + i]; pay[k] = v.payload; key[k] = v.key - key_base; }
         }
     };
     auto process = [&](u64 (&pay)[TPT], KeyT (&key)[TPT], u64 tb, auto full_tag) {
@@ -919,8 +1006,8 @@ k_scatter_wcn(const Tup *__restrict__ in, const u64 *__restrict__ inP, const u32
                 const u32 d = dg[k];
                 const u32 p = P[d], heads = (p >> 16) & 0xffu;
                 const u32 slot = rk[k] < heads ? (u32)TILE + d * GR + (p >> 24) + rk[k] : (p & 0xffffu) + rk[k] - heads;
-                sp[slot] = pay[k];
-                sk[slot] = (u32)key[k];
+                sp[slot] = (pay[k] & tag_keep) | tag_or;                     // (the digit of a staged payload is re-derived from bits
+                sk[slot] = (u32)key[k];                                      //  >= shift >= tag.bits: untouched by the tag)
             }
         }
         __syncthreads();                                                     // D: carry heads + staging complete
@@ -991,6 +1078,25 @@ k_scatter_wcn(const Tup *__restrict__ in, const u64 *__restrict__ inP, const u32
     if constexpr (!IN_NARROW) {
         if (__ballot(ovf != 0) != 0 && lane == 0) atomicOr(overflow, 1u);
     }
+}
+
+// Contract check of the public stage call rhj_bucket_join before it routes to the compact-table kernel, which compares
+// only (payload >> radix_bits): inside every partition the low radix_bits payload bits of both sides must be one value.
+// One workgroup per partition (grid-stride); *bad is OR-ed with 1 otherwise.
+__global__ void __launch_bounds__(256)
+k_check_radix(const Tup *__restrict__ R, const u64 *__restrict__ startR, const Tup *__restrict__ S, const u64 *__restrict__ startS,
+              u64 nparts, int radix_bits, u64 *__restrict__ bad)
+{
+    const u64 mask = ((u64)1 << radix_bits) - 1;
+    u64 diff = 0;
+    for (u64 k = blockIdx.x; k < nparts; k += gridDim.x) {
+        const u64 r0 = startR[k], r1 = startR[k + 1], s0 = startS[k], s1 = startS[k + 1];
+        if (r0 == r1 && s0 == s1) continue;
+        const u64 ref = r0 < r1 ? R[r0].payload : S[s0].payload;
+        for (u64 i = r0 + threadIdx.x; i < r1; i += 256) diff |= (R[i].payload ^ ref) & mask;
+        for (u64 i = s0 + threadIdx.x; i < s1; i += 256) diff |= (S[i].payload ^ ref) & mask;
+    }
+    if (__ballot(diff != 0) != 0 && (threadIdx.x & 63) == 0) atomicOr((unsigned long long *)bad, 1ull);
 }
 
 // d_hist[b] = d_start[b+1] - d_start[b]
@@ -1186,14 +1292,21 @@ template <> struct RelView<true> {
     __device__ __forceinline__ u64 payload(u32 i) const { return p[i]; }
     __device__ __forceinline__ Rid rowid(u32 i) const { return k[i]; }
     __device__ __forceinline__ Both both(u32 i) const { return Both{k[i], p[i]}; }
+    __device__ __forceinline__ unsigned char tag(u32 i) const { return reinterpret_cast<const unsigned char *>(p)[(size_t)i * 8]; }   // low payload byte
 };
 
-template <int THREADS, int CHUNK, int BBITS, int EPT, bool DIRECT, bool NARROW = false>
+// TAGGED / tag_base / skip: as in k_join_ct (multi-GPU receiver: sender number in the low TAG_BITS payload bits, rowIDs
+// local to the sender's shard).  Payloads are compared with the tag bits forced to 1 on both sides.
+template <int THREADS, int CHUNK, int BBITS, int EPT, bool DIRECT, bool NARROW = false, bool TAGGED = false>
 __global__ void __launch_bounds__(THREADS, 4)
 k_join_bkt(const RelView<NARROW> R, const RelView<NARROW> S, const JoinTask *__restrict__ tasks,
            const u32 *__restrict__ ntasks, int radix_bits, Pair *__restrict__ out, u64 out_capacity,
-           u64 *__restrict__ out_count, DirectJoin dj)
+           u64 *__restrict__ out_count, DirectJoin dj, const u64 *__restrict__ tag_base = nullptr,
+           const u32 *__restrict__ skip = nullptr)
 {
+    static_assert(!TAGGED || (NARROW && !DIRECT), "sender tags exist in the narrow format only");
+    if (skip != nullptr && *skip != 0) return;
+    constexpr u64 TM = TAGGED ? (u64)(TAG_MAX - 1) : 0ull;                    // compare payloads with these bits set
     constexpr int NB = 1 << BBITS;
     constexpr int NW = THREADS / 64;
     constexpr int TILE = THREADS * EPT;
@@ -1206,6 +1319,7 @@ k_join_bkt(const RelView<NARROW> R, const RelView<NARROW> S, const JoinTask *__r
     u32 *wtot = off + NB + 4;                                                // 64: [slot][wave] match totals
     u32 *wsum = wtot + 64;                                                   // NW scan scratch
     u64 *gres = reinterpret_cast<u64 *>(wsum + NW);                          // 1
+    u64 *tbase = gres + 1;                                                   // TAGGED: 2 x TAG_MAX rowID bases (R's, then S's)
 
     JoinTask task;
     if (DIRECT) {
@@ -1225,6 +1339,10 @@ k_join_bkt(const RelView<NARROW> R, const RelView<NARROW> S, const JoinTask *__r
     const RelView<NARROW> P = (build_is_S ? R : S).at(task.pbeg);
     const u32 nb = task.blen, np = task.plen;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    if (TAGGED && tid < (int)(2 * TAG_MAX)) tbase[tid] = tag_base[tid];     // (visible after the first barrier of the build)
+    const u32 btoff = build_is_S ? TAG_MAX : 0u, ptoff = build_is_S ? 0u : TAG_MAX;
+    // rowID a pair reports for a probe tuple
+    auto probe_rowid = [&](const Both &t) -> u64 { return TAGGED ? (u64)t.key + tbase[ptoff + ((u32)t.payload & (u32)TM)] : (u64)t.key; };
 
     // first probe tile: in flight while the table is built
     Both p[EPT];
@@ -1269,8 +1387,8 @@ k_join_bkt(const RelView<NARROW> R, const RelView<NARROW> S, const JoinTask *__r
             const u32 i = (u32)k * THREADS + tid;
             if (i < nc) {
                 const u32 pos = off[bj_bucket<BBITS>(bt[k].payload, radix_bits)] + br[k];
-                keys[pos] = bt[k].payload;
-                rids[pos] = bt[k].key;
+                keys[pos] = bt[k].payload | TM;
+                rids[pos] = TAGGED ? (u64)bt[k].key + tbase[btoff + ((u32)bt[k].payload & (u32)TM)] : (u64)bt[k].key;
             }
         }
         __syncthreads();
@@ -1299,12 +1417,12 @@ k_join_bkt(const RelView<NARROW> R, const RelView<NARROW> S, const JoinTask *__r
                 unsigned long long heavy = __ballot(hi - lo > BJ_HEAVY);
                 const bool coop = heavy != 0 && __popcll(heavy) <= BJ_HEAVY_LANES;
                 if (!coop || hi - lo <= BJ_HEAVY)
-                    for (u32 j = lo; j < hi; j++) cnt[k] += (keys[j] == p[k].payload) ? 1u : 0u;
+                    for (u32 j = lo; j < hi; j++) cnt[k] += (keys[j] == (p[k].payload | TM)) ? 1u : 0u;
                 if (coop) {
                     while (heavy) {
                         const int leader = __ffsll((long long)heavy) - 1;
                         heavy &= heavy - 1;
-                        const u64 key = bj_readlane64(p[k].payload, leader);
+                        const u64 key = bj_readlane64(p[k].payload | TM, leader);
                         const u32 l = __builtin_amdgcn_readlane(lo, leader), hh = __builtin_amdgcn_readlane(hi, leader);
                         u32 tot = 0;
                         for (u32 j = l; j < hh; j += 64) {
@@ -1352,11 +1470,12 @@ k_join_bkt(const RelView<NARROW> R, const RelView<NARROW> S, const JoinTask *__r
                     const bool coop = heavy != 0 && __popcll(heavy) <= BJ_HEAVY_LANES;
                     if (cnt[k] && (!coop || hi - lo <= BJ_HEAVY)) {
                         for (u32 j = lo; j < hi; j++) {
-                            if (keys[j] == p[k].payload) {
+                            if (keys[j] == (p[k].payload | TM)) {
                                 if (o < out_capacity) {
+                                    const u64 pk = probe_rowid(p[k]);
                                     Pair pr;
-                                    if (build_is_S) { pr.r = p[k].key; pr.s = rids[j]; }   // orderFlag, Result.cpp:64-68
-                                    else            { pr.r = rids[j]; pr.s = p[k].key; }
+                                    if (build_is_S) { pr.r = pk; pr.s = rids[j]; }         // orderFlag, Result.cpp:64-68
+                                    else            { pr.r = rids[j]; pr.s = pk; }
                                     out[o] = pr;
                                     if (DIRECT && o < dj.host_cap) dj.host_out[o] = pr;
                                 }
@@ -1369,8 +1488,8 @@ k_join_bkt(const RelView<NARROW> R, const RelView<NARROW> S, const JoinTask *__r
                         while (heavy) {
                             const int leader = __ffsll((long long)heavy) - 1;
                             heavy &= heavy - 1;
-                            const u64 key = bj_readlane64(p[k].payload, leader);
-                            const u64 pkey = bj_readlane64((u64)p[k].key, leader);
+                            const u64 key = bj_readlane64(p[k].payload | TM, leader);
+                            const u64 pkey = bj_readlane64(probe_rowid(p[k]), leader);
                             u64 ob = bj_readlane64(o, leader);
                             const u32 l = __builtin_amdgcn_readlane(lo, leader), hh = __builtin_amdgcn_readlane(hi, leader);
                             for (u32 j = l; j < hh; j += 64) {
@@ -1459,12 +1578,20 @@ __device__ __forceinline__ u32 ct_bucket(u64 key)
 // boundaries into `stamps` (CT_NSTAMP words per workgroup); never set in production launches.
 constexpr int CT_NSTAMP = 16;
 
-template <int THREADS, int CHUNK, int BBITS, int EPT, bool STAMPS, bool NARROW>
+// TAGGED (multi-GPU receiver, NARROW only): the low TAG_BITS bits of every payload hold the number of the rank the tuple
+// came from (written by the last partition pass, k_scatter_wcn's WnTag) and its rowID is local to that rank's shard: the
+// rowID a pair reports is tag_base[side][tag] + rowID32.  The tags ride through the kernel packed 4 bits per slot.
+// skip (optional): a device word that is non-zero when this join is going to be repeated in another format (a rowID did
+// not fit the narrow format): nothing to do then.
+template <int THREADS, int CHUNK, int BBITS, int EPT, bool STAMPS, bool NARROW, bool TAGGED = false>
 __global__ void __launch_bounds__(THREADS, THREADS * (CHUNK <= 8960 ? 2 : 1) / 256)   // wavefronts per SIMD: 2 (256 registers per lane) or 4 (128)
 k_join_ct(const RelView<NARROW> R, const RelView<NARROW> S, const JoinTask *__restrict__ tasks,
           const u32 *__restrict__ ntasks, int radix_bits, Pair *__restrict__ out, u64 out_capacity,
-          u64 *__restrict__ out_count, u64 *__restrict__ stamps, u32 nstamp_wgs)
+          u64 *__restrict__ out_count, u64 *__restrict__ stamps, u32 nstamp_wgs, const u64 *__restrict__ tag_base,
+          const u32 *__restrict__ skip)
 {
+    static_assert(!TAGGED || NARROW, "sender tags exist in the narrow format only");
+    if (skip != nullptr && *skip != 0) return;
     int stamp_i = 0;
     auto stamp = [&]() {
         if (STAMPS && threadIdx.x == 0 && blockIdx.x < nstamp_wgs && stamp_i < CT_NSTAMP)
@@ -1490,11 +1617,14 @@ k_join_ct(const RelView<NARROW> R, const RelView<NARROW> S, const JoinTask *__re
     u64 *dummy = gres + 1;                                                   // target of the LDS writes of out-of-range slots:
     // range checks select an address instead of branching, so that the reads / atomics of a whole batch are in
     // flight together (a branch per slot costs one exposed LDS round trip each: measured 35 of them per build phase)
+    u64 *tbase = dummy + 1;                                                  // TAGGED: 2 x TAG_MAX rowID bases (R's, then S's)
 
     const u32 nt = *ntasks;
     if (blockIdx.x >= nt) return;
     const JoinTask task = tasks[blockIdx.x];
     const bool build_is_S = task.build_is_S != 0;
+    if (TAGGED && threadIdx.x < 2 * TAG_MAX) tbase[threadIdx.x] = tag_base[threadIdx.x];   // (visible after the first barrier)
+    const u32 btoff = build_is_S ? TAG_MAX : 0u, ptoff = build_is_S ? 0u : TAG_MAX;
     typedef typename RelView<NARROW>::Rid Rid;
     typedef typename RelView<NARROW>::Both Both;
     const RelView<NARROW> B = (build_is_S ? S : R).at(task.bbeg);
@@ -1572,6 +1702,9 @@ k_join_ct(const RelView<NARROW> R, const RelView<NARROW> S, const JoinTask *__re
                                                                              // (bit b: entry lo + b matches) << 16; 0 = none
         u32 deferred = 0;                                                    // wave-uniform: slots left to the generic loop
         u32 ctot = 0;                                                        // matches of this lane
+        // TAGGED: the sender tag of a probe slot rides in mi[k] between the position and a match mask of 12 instead of 16 bits
+        // (buckets average 1.9 entries; longer ones go through the generic loop): no register of its own
+        constexpr u32 MB = TAGGED ? CT_MASK_BITS - TAG_BITS : CT_MASK_BITS, MSH = 32 - MB;
         Both ring[DEPTH][PT];
         asm volatile("" : "+v"(tid), "+v"(nv));
 #pragma unroll
@@ -1590,7 +1723,8 @@ k_join_ct(const RelView<NARROW> R, const RelView<NARROW> S, const JoinTask *__re
                 const u32 h = ct_bucket<BBITS>(key);
                 khi[s] = (u32)(key >> 16); klo[s] = (u32)key << 16;
                 lo[s] = off16[h]; m[s] = 0;
-                len[s] = k < nv ? off16[h + 1] - lo[s] : 0u;
+                if (TAGGED) lo[s] |= ((u32)ring[t % DEPTH][s].payload & (TAG_MAX - 1)) << 16;
+                len[s] = k < nv ? off16[h + 1] - (lo[s] & 0xFFFFu) : 0u;
                 maxlen = len[s] > maxlen ? len[s] : maxlen;
             }
             if (t + DEPTH < NT) {                                            // the slot is free: next tile on its way
@@ -1598,14 +1732,14 @@ k_join_ct(const RelView<NARROW> R, const RelView<NARROW> S, const JoinTask *__re
                 for (int s = 0; s < PT; s++)
                     ring[t % DEPTH][s] = P.both((t + DEPTH) * PT + s < nv ? (u32)((t + DEPTH) * PT + s) * THREADS + tid : 0u);
             }
-            const bool longb = __ballot(maxlen > CT_MASK_BITS) != 0;         // a long bucket somewhere: the generic loop
+            const bool longb = __ballot(maxlen > MB) != 0;                   // a long bucket somewhere: the generic loop
             if (!longb) {
                 for (u32 j = 0; __ballot(j < maxlen) != 0; j++) {            // PT independent LDS reads per round
 #pragma unroll
                     for (int s = 0; s < PT; s++) {
-                        const u64 e = ent[lo[s] + j];                        // (past the bucket's end: some other entry, ignored)
+                        const u64 e = ent[(lo[s] & 0xFFFFu) + j];            // (past the bucket's end: some other entry, ignored)
                         const u32 xl = (u32)e ^ klo[s], xh = (u32)(e >> 32) ^ khi[s];
-                        if (j < len[s] && xh == 0 && xl < 0x10000u) m[s] |= 0x10000u << j;
+                        if (j < len[s] && xh == 0 && xl < 0x10000u) m[s] |= (1u << MSH) << j;
                     }
                 }
             }
@@ -1613,7 +1747,7 @@ k_join_ct(const RelView<NARROW> R, const RelView<NARROW> S, const JoinTask *__re
             for (int s = 0; s < PT; s++) {
                 const int k = t * PT + s;
                 if (longb) { deferred |= 1u << k; m[s] = 0; }
-                ctot += (u32)__popc(m[s] >> 16);
+                ctot += (u32)__popc(m[s] >> MSH);
                 mi[k] = m[s] ? (m[s] | lo[s]) : 0u;
             }
         }
@@ -1629,6 +1763,11 @@ k_join_ct(const RelView<NARROW> R, const RelView<NARROW> S, const JoinTask *__re
             deferred &= deferred - 1;
             const Both pt = P.both(k < nv ? (u32)k * THREADS + tid : 0u);
             const u64 key = pt.payload >> rb;
+            const u64 ptkey = TAGGED ? (u64)pt.key + tbase[ptoff + ((u32)pt.payload & (TAG_MAX - 1))] : (u64)pt.key;
+            // build rowID of arrival index i (TAGGED: + the base of the rank named in the low bits of its payload)
+            auto build_rowid = [&](u32 i) -> u64 {
+                return TAGGED ? (u64)B.rowid(i) + tbase[btoff + ((u32)B.payload(i) & (TAG_MAX - 1))] : (u64)B.rowid(i);
+            };
             u32 lo = 0, hi = 0;
             if (k < nv) { const u32 h = ct_bucket<BBITS>(key); lo = off16[h]; hi = off16[h + 1]; }
             unsigned long long heavy = __ballot(hi - lo > BJ_HEAVY);
@@ -1664,9 +1803,9 @@ k_join_ct(const RelView<NARROW> R, const RelView<NARROW> S, const JoinTask *__re
                     const u64 e = ent[j];
                     if ((e >> 16) == key) {
                         if (o < out_capacity) {
-                            const u64 br = B.rowid(cb + ((u32)e & 0xFFFFu));
+                            const u64 br = build_rowid(cb + ((u32)e & 0xFFFFu));
                             Pair pr;
-                            if (build_is_S) { pr.r = pt.key; pr.s = br; } else { pr.r = br; pr.s = pt.key; }
+                            if (build_is_S) { pr.r = ptkey; pr.s = br; } else { pr.r = br; pr.s = ptkey; }
                             out[o] = pr;
                         }
                         o++;
@@ -1678,7 +1817,7 @@ k_join_ct(const RelView<NARROW> R, const RelView<NARROW> S, const JoinTask *__re
                 while (hv) {
                     const int leader = __ffsll((long long)hv) - 1;
                     hv &= hv - 1;
-                    const u64 lkey = bj_readlane64(key, leader), lprid = bj_readlane64((u64)pt.key, leader);
+                    const u64 lkey = bj_readlane64(key, leader), lprid = bj_readlane64(ptkey, leader);
                     u64 ob = bj_readlane64(o, leader);
                     const u32 l = __builtin_amdgcn_readlane(lo, leader), hh = __builtin_amdgcn_readlane(hi, leader);
                     for (u32 j = l; j < hh; j += 64) {
@@ -1688,7 +1827,7 @@ k_join_ct(const RelView<NARROW> R, const RelView<NARROW> S, const JoinTask *__re
                         const unsigned long long bal = __ballot(mt);
                         const u64 dst = ob + (u64)__popcll(bal & lt);
                         if (mt && dst < out_capacity) {
-                            const u64 br = B.rowid(cb + ((u32)e & 0xFFFFu));
+                            const u64 br = build_rowid(cb + ((u32)e & 0xFFFFu));
                             Pair pr;
                             if (build_is_S) { pr.r = lprid; pr.s = br; } else { pr.r = br; pr.s = lprid; }
                             out[dst] = pr;
@@ -1705,13 +1844,18 @@ k_join_ct(const RelView<NARROW> R, const RelView<NARROW> S, const JoinTask *__re
         // take 70 more VGPRs through the probe phase (tried: the allocator spills them at their definition and the
         // build loads serialise behind the scratch stores); they are fetched again here instead, 8 of every 16 bytes of
         // a partition this CU streamed a few microseconds ago, while the barrier and the reservation go on.
+        // TAGGED: the sender tags of the build tuples (low byte of their payloads) are fetched again too, once the rowIDs
+        // are in LDS (three more registers held through the probe phase cost 44 spilled VGPRs, eighteen more here 34).
         Rid brid[BPT];
         {
             int tq = tid0;
             asm volatile("" : "+v"(tq));
             const int nvq = nc > (u32)tq ? (int)((nc - (u32)tq + THREADS - 1) / THREADS) : 0;
 #pragma unroll
-            for (int k = 0; k < BPT; k++) brid[k] = B.rowid(cb + (k < nvq ? (u32)k * THREADS + tq : 0u));
+            for (int k = 0; k < BPT; k++) {
+                const u32 i = cb + (k < nvq ? (u32)k * THREADS + tq : 0u);
+                brid[k] = B.rowid(i);
+            }
         }
         stamp();                                                             // 5: rowID loads issued
         if (lane == 0) wtot[w] = wave_total;
@@ -1722,8 +1866,17 @@ k_join_ct(const RelView<NARROW> R, const RelView<NARROW> S, const JoinTask *__re
             asm volatile("" : "+v"(td));
             const int nvd = nc > (u32)td ? (int)((nc - (u32)td + THREADS - 1) / THREADS) : 0;
 #pragma unroll
-            for (int k = 0; k < BPT; k++)
-                *(k < nvd ? &rid[(k & 1) ? (ppos[k >> 1] >> 16) : (ppos[k >> 1] & 0xFFFFu)] : dummy) = brid[k];   // table order
+            for (int k = 0; k < BPT; k++) {
+                *(k < nvd ? &rid[(k & 1) ? (ppos[k >> 1] >> 16) : (ppos[k >> 1] & 0xFFFFu)] : dummy) = (u64)brid[k];   // table order
+            }
+        }
+        unsigned char btg[TAGGED ? BPT : 1];                                 // (the rowID registers are free again)
+        if constexpr (TAGGED) {
+            int tg = tid0;
+            asm volatile("" : "+v"(tg));
+            const int nvg = nc > (u32)tg ? (int)((nc - (u32)tg + THREADS - 1) / THREADS) : 0;
+#pragma unroll
+            for (int k = 0; k < BPT; k++) btg[k] = B.tag(cb + (k < nvg ? (u32)k * THREADS + tg : 0u));
         }
         stamp();                                                             // 7: rowIDs in LDS
         const u32 mine = lane < NW ? wtot[lane] : 0u;
@@ -1731,6 +1884,17 @@ k_join_ct(const RelView<NARROW> R, const RelView<NARROW> S, const JoinTask *__re
         const u32 chunk_total = __shfl(inc, NW - 1, 64);
         const u32 wbase = __shfl(inc - mine, w, 64);
         if (tid == 0 && chunk_total) *gres = atomicAdd(out_count, (u64)chunk_total);
+        if constexpr (TAGGED) {                                              // rid[pos] = {sender | local rowID}, resolved when a pair is stored
+            int th = tid0;
+            asm volatile("" : "+v"(th));
+            const int nvh = nc > (u32)th ? (int)((nc - (u32)th + THREADS - 1) / THREADS) : 0;
+            unsigned char *rb8 = reinterpret_cast<unsigned char *>(rid);
+#pragma unroll
+            for (int k = 0; k < BPT; k++) {
+                const u32 pos = (k & 1) ? (ppos[k >> 1] >> 16) : (ppos[k >> 1] & 0xFFFFu);
+                *(k < nvh ? &rb8[(size_t)pos * 8 + 4] : reinterpret_cast<unsigned char *>(dummy)) = btg[k] & (unsigned char)(TAG_MAX - 1);
+            }
+        }
         __syncthreads();
         stamp();                                                             // 8: output reserved
         if (out != nullptr && wave_total) {
@@ -1738,7 +1902,7 @@ k_join_ct(const RelView<NARROW> R, const RelView<NARROW> S, const JoinTask *__re
 #pragma unroll
             for (int k = 0; k < EPT; k++) {
                 const u32 lo = mi[k] & 0xFFFFu;
-                u32 mask = mi[k] >> 16;
+                u32 mask = mi[k] >> MSH;
                 // round r stores the (r+1)-th match of every lane that has one: ballot + mbcnt compaction, consecutive
                 // lanes -> consecutive pairs.  One round in the FK case; no cross-lane scan with duplicates either.
                 for (unsigned long long bal = __ballot(mask != 0); bal != 0; bal = __ballot(mask != 0)) {
@@ -1747,10 +1911,15 @@ k_join_ct(const RelView<NARROW> R, const RelView<NARROW> S, const JoinTask *__re
                         const u32 bpos = (u32)__ffs((int)mask) - 1;
                         mask &= mask - 1;
                         if (dst < out_capacity) {
-                            const u64 br = rid[lo + bpos];
+                            u64 br = rid[lo + bpos];
+                            u64 pk = prid[k];
+                            if (TAGGED) {
+                                br = (u64)(u32)br + tbase[btoff + (u32)(br >> 32)];
+                                pk += tbase[ptoff + ((mi[k] >> 16) & (TAG_MAX - 1))];
+                            }
                             Pair pr;
-                            if (build_is_S) { pr.r = prid[k]; pr.s = br; }      // orderFlag, Result.cpp:64-68
-                            else            { pr.r = br; pr.s = prid[k]; }
+                            if (build_is_S) { pr.r = pk; pr.s = br; }           // orderFlag, Result.cpp:64-68
+                            else            { pr.r = br; pr.s = pk; }
                             typedef u64 u64x2 __attribute__((ext_vector_type(2)));
                             __builtin_nontemporal_store(u64x2{pr.r, pr.s}, reinterpret_cast<u64x2 *>(out + dst));
                         }
@@ -1875,7 +2044,7 @@ int join_ct_min_radix_bits() { return CT_MIN_RADIX_BITS; }
 
 static size_t bj_lds_bytes(int threads, int chunk, int bbits)
 {
-    return (size_t)chunk * 16 + ((size_t)(1 << bbits) + 4) * 4 + 64 * 4 + (size_t)(threads / 64) * 4 + 16;
+    return (size_t)chunk * 16 + ((size_t)(1 << bbits) + 4) * 4 + 64 * 4 + (size_t)(threads / 64) * 4 + 16 + 2 * TAG_MAX * 8;
 }
 
 // Per device (a process may drive several GPUs through different contexts) and exactly once: contexts of
@@ -1890,51 +2059,54 @@ static int current_device_slot()
 
 static size_t ct_lds_bytes(int threads = CT_THREADS, int chunk = CT_CHUNK, int bbits = CT_BUCKET_BITS)
 {
-    return (size_t)chunk * 8 + ((size_t)(1 << bbits) / 2 + 2 + 2 * (threads / 64)) * 4 + 24;
+    return (size_t)chunk * 8 + ((size_t)(1 << bbits) / 2 + 2 + 2 * (threads / 64)) * 4 + 24 + 2 * TAG_MAX * 8;
 }
+
+// hipFuncSetAttribute results are kept: a refused LDS size would otherwise surface later as an anonymous launch failure.
+// rhj_api.hip reads the text through launch_attr_error() in check_launch().
+static std::mutex g_attr_mu;
+static std::string g_attr_error;
+
+const char *launch_attr_error()
+{
+    std::lock_guard<std::mutex> lk(g_attr_mu);
+    return g_attr_error.empty() ? nullptr : g_attr_error.c_str();
+}
+
+static void set_lds(const void *fn, size_t bytes, const char *name)
+{
+    const hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+    if (e == hipSuccess) return;
+    (void)hipGetLastError();
+    std::lock_guard<std::mutex> lk(g_attr_mu);
+    if (g_attr_error.empty())
+        g_attr_error = std::string("hipFuncSetAttribute(") + name + ", dynamic LDS " + std::to_string(bytes) + " B): " + hipGetErrorString(e);
+}
+#define SET_LDS(fn, bytes) set_lds(reinterpret_cast<const void *>(&fn), (bytes), #fn)
 
 static void allow_big_lds()
 {
     static std::once_flag done[64];
     std::call_once(done[current_device_slot()], [] {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_scatter_units_pipe),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)part_lds_bytes(PART_MAX_BITS));
-    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_scatter_wc<WC_THREADS>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)wc_lds_bytes(WC_MAX_BITS, WC_THREADS));
-    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_scatter_wc<WC_THREADS_SMALL>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)wc_lds_bytes(WC_MAX_BITS, WC_THREADS_SMALL));
-    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_scatter_wc2<WC_THREADS>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)wc_lds_bytes(WC_MAX_BITS, WC_THREADS));
-    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_scatter_wc2<WC_THREADS_SMALL>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)wc_lds_bytes(WC_MAX_BITS, WC_THREADS_SMALL));
-    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_join_bkt<BJ_THREADS, BJ_CHUNK, BJ_BUCKET_BITS, BJ_EPT, false>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize,
-                              (int)bj_lds_bytes(BJ_THREADS, BJ_CHUNK, BJ_BUCKET_BITS));
-    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_join_bkt<BJ_THREADS, BJ_CHUNK, BJ_BUCKET_BITS, BJ_EPT, true>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize,
-                              (int)bj_lds_bytes(BJ_THREADS, BJ_CHUNK, BJ_BUCKET_BITS));
-    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_join_bkt<BJ_THREADS, BJ_CHUNK, BJ_BUCKET_BITS, BJ_EPT, false, true>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize,
-                              (int)bj_lds_bytes(BJ_THREADS, BJ_CHUNK, BJ_BUCKET_BITS));
-    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_join_bkt<BJ2_THREADS, BJ2_CHUNK, BJ2_BUCKET_BITS, BJ2_EPT, false>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize,
-                              (int)bj_lds_bytes(BJ2_THREADS, BJ2_CHUNK, BJ2_BUCKET_BITS));
-    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_join_ct<CT_THREADS, CT_CHUNK, CT_BUCKET_BITS, CT_EPT, false, false>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)ct_lds_bytes());
-    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_join_ct<CTH_THREADS, CTH_CHUNK, CTH_BUCKET_BITS, CT_EPT, false, false>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize,
-                              (int)ct_lds_bytes(CTH_THREADS, CTH_CHUNK, CTH_BUCKET_BITS));
-    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_join_ct<CT_THREADS, CT_CHUNK, CT_BUCKET_BITS, CT_EPT, true, false>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)ct_lds_bytes());
-    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_join_ct<CT_THREADS, CT_CHUNK, CT_BUCKET_BITS, CT_EPT, false, true>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)ct_lds_bytes());
-    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_join_ct<CTH_THREADS, CTH_CHUNK, CTH_BUCKET_BITS, CT_EPT, false, true>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize,
-                              (int)ct_lds_bytes(CTH_THREADS, CTH_CHUNK, CTH_BUCKET_BITS));
-    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_scatter_wcn<false>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)wn_lds_bytes(WN_MAX_BITS));
-    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_scatter_wcn<true>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)wn_lds_bytes(WN_MAX_BITS));
+    SET_LDS(k_scatter_units_pipe, part_lds_bytes(PART_MAX_BITS));
+    SET_LDS(k_scatter_wc<WC_THREADS>, wc_lds_bytes(WC_MAX_BITS, WC_THREADS));
+    SET_LDS(k_scatter_wc<WC_THREADS_SMALL>, wc_lds_bytes(WC_MAX_BITS, WC_THREADS_SMALL));
+    SET_LDS(k_scatter_wc2<WC_THREADS>, wc_lds_bytes(WC_MAX_BITS, WC_THREADS));
+    SET_LDS(k_scatter_wc2<WC_THREADS_SMALL>, wc_lds_bytes(WC_MAX_BITS, WC_THREADS_SMALL));
+    SET_LDS((k_join_bkt<BJ_THREADS, BJ_CHUNK, BJ_BUCKET_BITS, BJ_EPT, false>), bj_lds_bytes(BJ_THREADS, BJ_CHUNK, BJ_BUCKET_BITS));
+    SET_LDS((k_join_bkt<BJ_THREADS, BJ_CHUNK, BJ_BUCKET_BITS, BJ_EPT, true>), bj_lds_bytes(BJ_THREADS, BJ_CHUNK, BJ_BUCKET_BITS));
+    SET_LDS((k_join_bkt<BJ_THREADS, BJ_CHUNK, BJ_BUCKET_BITS, BJ_EPT, false, true>), bj_lds_bytes(BJ_THREADS, BJ_CHUNK, BJ_BUCKET_BITS));
+    SET_LDS((k_join_bkt<BJ2_THREADS, BJ2_CHUNK, BJ2_BUCKET_BITS, BJ2_EPT, false>), bj_lds_bytes(BJ2_THREADS, BJ2_CHUNK, BJ2_BUCKET_BITS));
+    SET_LDS((k_join_ct<CT_THREADS, CT_CHUNK, CT_BUCKET_BITS, CT_EPT, false, false>), ct_lds_bytes());
+    SET_LDS((k_join_ct<CTH_THREADS, CTH_CHUNK, CTH_BUCKET_BITS, CT_EPT, false, false>), ct_lds_bytes(CTH_THREADS, CTH_CHUNK, CTH_BUCKET_BITS));
+    SET_LDS((k_join_ct<CT_THREADS, CT_CHUNK, CT_BUCKET_BITS, CT_EPT, true, false>), ct_lds_bytes());
+    SET_LDS((k_join_ct<CT_THREADS, CT_CHUNK, CT_BUCKET_BITS, CT_EPT, false, true>), ct_lds_bytes());
+    SET_LDS((k_join_ct<CTH_THREADS, CTH_CHUNK, CTH_BUCKET_BITS, CT_EPT, false, true>), ct_lds_bytes(CTH_THREADS, CTH_CHUNK, CTH_BUCKET_BITS));
+    SET_LDS((k_join_bkt<BJ_THREADS, BJ_CHUNK, BJ_BUCKET_BITS, BJ_EPT, false, true, true>), bj_lds_bytes(BJ_THREADS, BJ_CHUNK, BJ_BUCKET_BITS));
+    SET_LDS((k_join_ct<CT_THREADS, CT_CHUNK, CT_BUCKET_BITS, CT_EPT, false, true, true>), ct_lds_bytes());
+    SET_LDS((k_join_ct<CTH_THREADS, CTH_CHUNK, CTH_BUCKET_BITS, CT_EPT, false, true, true>), ct_lds_bytes(CTH_THREADS, CTH_CHUNK, CTH_BUCKET_BITS));
+    SET_LDS(k_scatter_wcn<false>, wn_lds_bytes(WN_MAX_BITS));
+    SET_LDS(k_scatter_wcn<true>, wn_lds_bytes(WN_MAX_BITS));
     });
 }
 
@@ -1949,11 +2121,11 @@ void launch_make_units(hipStream_t st, const u64 *d_seg_start, u32 nseg, u64 L, 
 }
 
 void launch_hist_units(hipStream_t st, const void *d_in, const PassGeom &g, const u64 *d_seg_start,
-                       const u32 *d_unit_start, u32 *d_unit_hist)
+                       const u32 *d_unit_start, u32 *d_unit_hist, u64 *d_minmax)
 {
     if (g.max_units == 0) return;
     hipLaunchKernelGGL(k_hist_units, dim3(g.max_units), dim3(PART_THREADS), ((size_t)4 << g.bits), st,
-                       (const Tup *)d_in, d_seg_start, d_unit_start, g.nseg, g.L, g.shift, g.bits, d_unit_hist);
+                       (const Tup *)d_in, d_seg_start, d_unit_start, g.nseg, g.L, g.shift, g.bits, d_unit_hist, d_minmax);
 }
 
 void launch_scan_units(hipStream_t st, const PassGeom &g, const u64 *d_seg_start, const u32 *d_unit_start,
@@ -2035,19 +2207,38 @@ void launch_pass_pair(hipStream_t st, const PassPairHost &h, int shift, int bits
 
 bool fused_two_pass_ok(int b1, int b2) { return b1 >= 1 && b2 >= 1 && b1 <= WC_MAX_BITS && b2 <= WC_MAX_BITS && b1 + b2 <= 16; }
 
-void launch_hist2d_units(hipStream_t st, const void *d_in, u64 n, u64 L, u32 units, int b1, int b2,
-                         u32 units_per_group, u32 ngroups, u32 *d_hist1, u32 *d_hist2)
+void launch_hist2d_units(hipStream_t st, const void *d_in, bool in_narrow, u64 n, u64 L, u32 units, int b1, int b2,
+                         u32 units_per_group, u32 ngroups, u32 *d_hist1, u32 *d_hist2, u64 key_base, u32 *d_wide,
+                         const u64 *d_unit_rng)
 {
     static std::once_flag once[64];
     const size_t lds = ((size_t)1 << (b1 + b2)) * 2 + ((size_t)4 << b1);
     std::call_once(once[current_device_slot()], [] {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_hist2d_units),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)(((size_t)1 << 16) * 2 + ((size_t)4 << WC_MAX_BITS)));
+        SET_LDS(k_hist2d_units<false>, ((size_t)1 << 16) * 2 + ((size_t)4 << WC_MAX_BITS));
+        SET_LDS(k_hist2d_units<true>, ((size_t)1 << 16) * 2 + ((size_t)4 << WC_MAX_BITS));
     });
     if (units == 0) return;
-    hipLaunchKernelGGL(k_hist2d_units, dim3(units), dim3(H2_THREADS), lds, st, (const Tup *)d_in, n, L, b1, b2,
-                       units_per_group, ngroups, d_hist1, d_hist2);
+    if (in_narrow)
+        hipLaunchKernelGGL(k_hist2d_units<true>, dim3(units), dim3(H2_THREADS), lds, st, (const Tup *)nullptr, (const u64 *)d_in, n,
+                           L, b1, b2, units_per_group, ngroups, d_hist1, d_hist2, (u64)0, (u32 *)nullptr, d_unit_rng);
+    else
+        hipLaunchKernelGGL(k_hist2d_units<false>, dim3(units), dim3(H2_THREADS), lds, st, (const Tup *)d_in, (const u64 *)nullptr, n,
+                           L, b1, b2, units_per_group, ngroups, d_hist1, d_hist2, key_base, d_wide, d_unit_rng);
 }
+
+// pass-1 units cut at segment boundaries (multi-GPU receiver); d_unit_rng gets nseg * units_per_seg + 1 entries
+void launch_seg_units(hipStream_t st, u32 nseg, const u64 *seg_off, const u64 *seg_L, u32 units_per_seg, u64 *d_unit_rng,
+                      u64 *d_seg_start, u32 *d_unit_start)
+{
+    SegPlan sp{};
+    sp.nseg = nseg;
+    sp.units_per_seg = units_per_seg;
+    for (u32 i = 0; i <= nseg && i <= SEG_MAX; i++) sp.off[i] = seg_off[i];
+    for (u32 i = 0; i < nseg && i < SEG_MAX; i++) sp.L[i] = seg_L[i];
+    const u32 total = nseg * units_per_seg + 1;
+    hipLaunchKernelGGL(k_seg_units, dim3((total + 255) / 256), dim3(256), 0, st, sp, d_unit_rng, d_seg_start, d_unit_start);
+}
+int seg_max() { return SEG_MAX; }
 
 void launch_make_group_ranges(hipStream_t st, const u64 *d_unit_base1, u32 nb1, u32 units_per_group, u32 ngroups, u64 n,
                               u64 *d_rng, u32 *d_unit_start2)
@@ -2077,32 +2268,46 @@ void launch_scatter_ranges(hipStream_t st, const void *d_in, void *d_out, u32 nu
 bool narrow_pass_ok(int bits) { return bits >= 1 && bits <= WN_MAX_BITS; }
 
 void launch_scatter_units_narrow(hipStream_t st, const void *d_in, void *d_out, u64 n, const PassGeom &g,
-                                 const u64 *d_seg_start, const u32 *d_unit_start, const u64 *d_unit_base, u32 *d_overflow)
+                                 const u64 *d_seg_start, const u32 *d_unit_start, const u64 *d_unit_base, u32 *d_overflow,
+                                 u64 key_base)
 {
     if (g.max_units == 0) return;
     allow_big_lds();
     hipLaunchKernelGGL(k_scatter_wcn<false>, dim3(g.max_units), dim3(WN_THREADS), wn_lds_bytes(g.bits), st, (const Tup *)d_in,
                        (const u64 *)nullptr, (const u32 *)nullptr, (u64 *)d_out,
                        (u32 *)((unsigned char *)d_out + narrow_k_offset(n)), d_seg_start, d_unit_start, g.nseg, g.L, g.shift,
-                       g.bits, d_unit_base, (const u64 *)nullptr, 0u, d_overflow);
+                       g.bits, d_unit_base, (const u64 *)nullptr, 0u, d_overflow, key_base, WnTag{1u, 1u, 0u});
 }
 
+// explicit unit ranges [d_rng[u], d_rng[u+1]); tag_groups / tag_div != 0: the low TAG_BITS bits of every payload written are
+// replaced by (u % tag_groups) / tag_div (see WnTag)
 void launch_scatter_ranges_narrow(hipStream_t st, const void *d_in, bool in_narrow, void *d_out, u64 n, u32 nunits, int shift,
-                                  int bits, const u64 *d_unit_base, const u64 *d_rng, u32 *d_overflow)
+                                  int bits, const u64 *d_unit_base, const u64 *d_rng, u32 *d_overflow, u32 tag_groups,
+                                  u32 tag_div, const u32 *d_inK)
 {
     if (nunits == 0) return;
     allow_big_lds();
     u64 *oP = (u64 *)d_out;
     u32 *oK = (u32 *)((unsigned char *)d_out + narrow_k_offset(n));
+    const WnTag tag = tag_div ? WnTag{tag_groups, tag_div, TAG_BITS} : WnTag{1u, 1u, 0u};
     if (in_narrow)
         hipLaunchKernelGGL(k_scatter_wcn<true>, dim3(nunits), dim3(WN_THREADS), wn_lds_bytes(bits), st, (const Tup *)nullptr,
-                           (const u64 *)d_in, (const u32 *)((const unsigned char *)d_in + narrow_k_offset(n)), oP, oK,
+                           (const u64 *)d_in, d_inK ? d_inK : (const u32 *)((const unsigned char *)d_in + narrow_k_offset(n)), oP, oK,
                            (const u64 *)nullptr, (const u32 *)nullptr, 0u, (u64)0, shift, bits, d_unit_base, d_rng, nunits,
-                           d_overflow);
+                           d_overflow, (u64)0, tag);
     else
         hipLaunchKernelGGL(k_scatter_wcn<false>, dim3(nunits), dim3(WN_THREADS), wn_lds_bytes(bits), st, (const Tup *)d_in,
                            (const u64 *)nullptr, (const u32 *)nullptr, oP, oK, (const u64 *)nullptr, (const u32 *)nullptr, 0u,
-                           (u64)0, shift, bits, d_unit_base, d_rng, nunits, d_overflow);
+                           (u64)0, shift, bits, d_unit_base, d_rng, nunits, d_overflow, (u64)0, tag);
+}
+int tag_bits() { return (int)TAG_BITS; }
+
+void launch_check_radix(hipStream_t st, const void *d_R, const u64 *d_startR, const void *d_S, const u64 *d_startS, u64 nparts,
+                        int radix_bits, u64 *d_bad)
+{
+    const unsigned grid = (unsigned)(nparts < 4096 ? nparts : 4096);
+    hipLaunchKernelGGL(k_check_radix, dim3(grid ? grid : 1), dim3(256), 0, st, (const Tup *)d_R, d_startR, (const Tup *)d_S, d_startS,
+                       nparts, radix_bits, d_bad);
 }
 
 void launch_diff_hist(hipStream_t st, const u64 *d_start, u64 nbins, u64 *d_hist)
@@ -2131,25 +2336,30 @@ void launch_make_tasks(hipStream_t st, const u64 *d_startR, const u64 *d_startS,
 
 void launch_join(hipStream_t st, const void *d_R, const u64 *d_startR, const void *d_S, const u64 *d_startS,
                  const JoinTask *d_tasks, const u32 *d_ntasks, u32 grid, int radix_bits,
-                 void *d_out, u64 out_capacity, u64 *d_out_count, int kind, const u32 *d_RK, const u32 *d_SK)
+                 void *d_out, u64 out_capacity, u64 *d_out_count, int kind, const u32 *d_RK, const u32 *d_SK,
+                 const u64 *d_tag_base, const u32 *d_skip)
 {
     if (grid == 0) return;
     allow_big_lds();
     const RelView<false> vR{(const Tup *)d_R}, vS{(const Tup *)d_S};
     if (d_RK != nullptr) {                                                   // narrow partitions (k_scatter_wcn): d_R, d_S are payload arrays
         const RelView<true> nR{(const u64 *)d_R, d_RK}, nS{(const u64 *)d_S, d_SK};
-        if (kind == JK_BKT)
-            hipLaunchKernelGGL((k_join_bkt<BJ_THREADS, BJ_CHUNK, BJ_BUCKET_BITS, BJ_EPT, false, true>), dim3(grid), dim3(BJ_THREADS),
-                               bj_lds_bytes(BJ_THREADS, BJ_CHUNK, BJ_BUCKET_BITS), st, nR, nS, d_tasks, d_ntasks, radix_bits,
-                               (Pair *)d_out, out_capacity, d_out_count, DirectJoin{});
-        else if (kind == JK_CT_HALF)
-            hipLaunchKernelGGL((k_join_ct<CTH_THREADS, CTH_CHUNK, CTH_BUCKET_BITS, CT_EPT, false, true>), dim3(grid), dim3(CTH_THREADS),
-                               ct_lds_bytes(CTH_THREADS, CTH_CHUNK, CTH_BUCKET_BITS), st, nR, nS, d_tasks, d_ntasks, radix_bits,
-                               (Pair *)d_out, out_capacity, d_out_count, (u64 *)nullptr, 0u);
-        else                                                                 // JK_CT (the host never asks for another kind here)
-            hipLaunchKernelGGL((k_join_ct<CT_THREADS, CT_CHUNK, CT_BUCKET_BITS, CT_EPT, false, true>), dim3(grid), dim3(CT_THREADS),
-                               ct_lds_bytes(), st, nR, nS, d_tasks, d_ntasks, radix_bits, (Pair *)d_out, out_capacity,
-                               d_out_count, (u64 *)nullptr, 0u);
+        Pair *o = (Pair *)d_out;
+#define LAUNCH_BKT_N(TG) hipLaunchKernelGGL((k_join_bkt<BJ_THREADS, BJ_CHUNK, BJ_BUCKET_BITS, BJ_EPT, false, true, TG>), dim3(grid), \
+            dim3(BJ_THREADS), bj_lds_bytes(BJ_THREADS, BJ_CHUNK, BJ_BUCKET_BITS), st, nR, nS, d_tasks, d_ntasks, radix_bits, o,       \
+            out_capacity, d_out_count, DirectJoin{}, d_tag_base, d_skip)
+#define LAUNCH_CT_N(T, C, B, TG) hipLaunchKernelGGL((k_join_ct<T, C, B, CT_EPT, false, true, TG>), dim3(grid), dim3(T),              \
+            ct_lds_bytes(T, C, B), st, nR, nS, d_tasks, d_ntasks, radix_bits, o, out_capacity, d_out_count, (u64 *)nullptr, 0u,      \
+            d_tag_base, d_skip)
+        const bool tg = d_tag_base != nullptr;
+        if (kind == JK_BKT) { if (tg) LAUNCH_BKT_N(true); else LAUNCH_BKT_N(false); }
+        else if (kind == JK_CT_HALF) {
+            if (tg) LAUNCH_CT_N(CTH_THREADS, CTH_CHUNK, CTH_BUCKET_BITS, true); else LAUNCH_CT_N(CTH_THREADS, CTH_CHUNK, CTH_BUCKET_BITS, false);
+        } else {                                                             // JK_CT (the host never asks for another kind here)
+            if (tg) LAUNCH_CT_N(CT_THREADS, CT_CHUNK, CT_BUCKET_BITS, true); else LAUNCH_CT_N(CT_THREADS, CT_CHUNK, CT_BUCKET_BITS, false);
+        }
+#undef LAUNCH_BKT_N
+#undef LAUNCH_CT_N
         return;
     }
     if (kind == JK_BKT) {
@@ -2167,18 +2377,19 @@ void launch_join(hipStream_t st, const void *d_R, const u64 *d_startR, const voi
     if (kind == JK_CT_HALF) {
         hipLaunchKernelGGL((k_join_ct<CTH_THREADS, CTH_CHUNK, CTH_BUCKET_BITS, CT_EPT, false, false>), dim3(grid), dim3(CTH_THREADS),
                            ct_lds_bytes(CTH_THREADS, CTH_CHUNK, CTH_BUCKET_BITS), st, vR, vS, d_tasks,
-                           d_ntasks, radix_bits, (Pair *)d_out, out_capacity, d_out_count, (u64 *)nullptr, 0u);
+                           d_ntasks, radix_bits, (Pair *)d_out, out_capacity, d_out_count, (u64 *)nullptr, 0u,
+                           (const u64 *)nullptr, (const u32 *)nullptr);
         return;
     }
     static const bool want_stamps = getenv("RHJ_CT_STAMPS") != nullptr;
-    if (want_stamps) {                                                       // tuning aid: phase timeline of the first workgroups
-        const u32 nw = grid < 4096 ? grid : 4096;
-        u64 *d_st = nullptr;
-        if (hipMalloc(&d_st, (size_t)nw * CT_NSTAMP * 8) != hipSuccess) return;
+    const u32 nw = grid < 4096 ? grid : 4096;
+    u64 *d_st = nullptr;
+    if (want_stamps && hipMalloc(&d_st, (size_t)nw * CT_NSTAMP * 8) != hipSuccess) { (void)hipGetLastError(); d_st = nullptr; }
+    if (d_st != nullptr) {                                                   // tuning aid: phase timeline of the first workgroups
         (void)hipMemsetAsync(d_st, 0, (size_t)nw * CT_NSTAMP * 8, st);
         hipLaunchKernelGGL((k_join_ct<CT_THREADS, CT_CHUNK, CT_BUCKET_BITS, CT_EPT, true, false>), dim3(grid), dim3(CT_THREADS),
                            ct_lds_bytes(), st, vR, vS, d_tasks, d_ntasks, radix_bits,
-                           (Pair *)d_out, out_capacity, d_out_count, d_st, nw);
+                           (Pair *)d_out, out_capacity, d_out_count, d_st, nw, (const u64 *)nullptr, (const u32 *)nullptr);
         std::vector<u64> h((size_t)nw * CT_NSTAMP);
         (void)hipMemcpyAsync(h.data(), d_st, h.size() * 8, hipMemcpyDeviceToHost, st);
         (void)hipStreamSynchronize(st);
@@ -2203,7 +2414,7 @@ void launch_join(hipStream_t st, const void *d_R, const u64 *d_startR, const voi
     }
     hipLaunchKernelGGL((k_join_ct<CT_THREADS, CT_CHUNK, CT_BUCKET_BITS, CT_EPT, false, false>), dim3(grid), dim3(CT_THREADS),
                        ct_lds_bytes(), st, vR, vS, d_tasks, d_ntasks, radix_bits,
-                       (Pair *)d_out, out_capacity, d_out_count, (u64 *)nullptr, 0u);
+                       (Pair *)d_out, out_capacity, d_out_count, (u64 *)nullptr, 0u, (const u64 *)nullptr, (const u32 *)nullptr);
 }
 
 // Unpartitioned join of two small relations in ONE launch: build side = S when nR >= nS (JobScheduler.cpp:187).

@@ -7,30 +7,43 @@ ONE exchange step, an all-to-all of tuples by OWNER CLASS:
     class(tuple) = (payload >> owner_shift) & (C - 1)         C = 2^fine_bits classes, C >> world
     owner(class) = the rank whose contiguous class range [cut[r], cut[r+1]) holds it
 
-  1. every rank splits its shards of R and S by class with one scatter-partition pass each
-     (rhj_partition_at): the tuples of a class, hence of a destination, become contiguous; the pass
-     also yields the shard's class histogram;
-  2. ONE all_gather of the (world x 2 x C) count matrix (tiny).  From it every rank derives, identically,
-     the class ranges: balanced so that every rank receives about (|R|+|S|) / world tuples whatever the skew
-     of the join values (a static `payload bits -> rank` map sends a Zipf foreign key's hot values, and everything
-     hashed next to them, to one rank) -- and the send / receive sizes of the tuple exchange;
-  3. ONE all_to_all_single of the tuples per relation (RCCL: world-1 direct peer sends over xGMI, all links
-     busy at once, no multi-hop); the exchange of S is in flight while the received R is radix-partitioned locally;
-  4. every rank now holds ALL tuples of its classes of both relations and runs the normal
-     single-GPU join (1-2 radix passes on the low bits + LDS bucket join) locally.
-     Class bits lie above every bit the local plan can use (2 * 10), so the local plan is untouched.
-Results stay sharded: rank d holds the pairs whose join value belongs to one of its classes; the global
+Schedule of the narrow path (include/rhj.h "multi-GPU stage entry points"; all compute in the C-ABI engine):
+
+  1. rhj_shard_stats on the shards of R and S: class histogram + rowID range (one 16 B/tuple read each);
+  2. ONE all_gather of {sizes, rowID ranges, the 2 x C class counts} (tiny).  From it every rank derives, identically,
+     the class ranges -- balanced so that every rank receives about (|R|+|S|) / world tuples whatever the skew of
+     the join values (a static `payload bits -> rank` map sends a Zipf foreign key's hot values, and everything
+     hashed next to them, to one rank) --, the send / receive counts, and the local radix plan (from the LARGEST
+     receive count, so that all ranks use the same bits);
+  3. rhj_shard_split: the class split writes the NARROW WIRE FORMAT, payload 8 B + (rowID - shard's smallest rowID) 4 B
+     in two arrays: 12 B/tuple cross xGMI instead of 16;
+  4. all_to_all_single of the payload array and of the rowID array per relation (RCCL: world-1 direct peer sends
+     over xGMI, all links busy at once, no multi-hop); R is on the wire while S is being split;
+  5. rhj_shard_partition: the local fused two-pass partition of what arrived (one 8 B/tuple histogram read, two
+     12 B + 12 B scatter passes); pass-1 units are cut at the sender segments of the receive buffer and pass 2 stamps
+     every tuple with its sender; the partitioning of R overlaps the transfer of S;
+  6. rhj_shard_join: the bucket join resolves sender + local rowID into the global rowID.
+Why the class split is NOT pass 1 of the local plan: two 8-bit passes separate 16 bits in all, and the
+ownership of a tuple uses up log2(world) of them -- 8 x 10^9 tuples need 19 bits, three passes, wherever the exchange sits.
+
+Everything is ordered on ONE stream (the engine is bound to torch's current stream; RCCL work objects make that
+stream wait): no host synchronisation except the count all_gather (sizes must be known on the host) and the result
+count.  Results stay sharded: rank d holds the pairs whose join value belongs to one of its classes; the global
 result is the disjoint union (counts add up, no reduction).
 
-All compute runs in the C-ABI engine passed in (HIP kernels); torch supplies device memory and the
-collectives.  The engine is duck-typed (partition_at, partition, bucket_join, join_dev) so the exchange logic
-can be tested on CPU ranks with the gloo backend (tests/test_sharded_gloo.py) and the whole path with the real
-engine and several ranks on one GPU (tests/test_gpu_sharded.py).
+Fallback (16-byte tuples on the wire; `rhj_shard_plan` says 0, or a shard's rowIDs span 2^32 or more, or more than 16
+ranks): rhj_partition_at class split -> all-to-all -> rhj_join_dev locally.
+
+The engine is duck-typed so the exchange logic can be tested on CPU ranks with the gloo backend
+(tests/test_sharded_gloo.py) and the whole path with the real engine and several ranks on one GPU
+(tests/test_gpu_sharded.py, tests/test_gpu_bench_multirank.py).
 """
+import numpy as np
 import torch
 import torch.distributed as dist
 
 OWNER_SHIFT_DEFAULT = 20      # above the 2 x 10 bits a local two-pass plan can use (PART_MAX_BITS = 10)
+MAX_NARROW_WORLD = 16         # sender tags are 4 bits (include/rhj.h)
 
 
 def balanced_cuts(weights, world):
@@ -51,15 +64,25 @@ def balanced_cuts(weights, world):
     return cuts
 
 
+def _i64(x):
+    """uint64 value -> the int64 with the same bits (torch has no uint64 collectives)"""
+    x = int(x) & ((1 << 64) - 1)
+    return x - (1 << 64) if x >= (1 << 63) else x
+
+
+def _u64(x):
+    return int(x) & ((1 << 64) - 1)
+
+
 class ShardedJoin:
     def __init__(self, engine, group=None, local_opts=None, owner_shift=OWNER_SHIFT_DEFAULT, fine_bits=None,
-                 balance=True):
+                 balance=True, narrow=True, bind_stream=True):
         self.engine = engine
         self.group = group if group is not None else dist.group.WORLD
         self.world = dist.get_world_size(self.group)
         self.rank = dist.get_rank(self.group)
-        if fine_bits is None:                # >= 32 classes per rank, within the full-rate range of the scatter kernel
-            fine_bits = min(9, max(8, (self.world - 1).bit_length() + 5))
+        if fine_bits is None:                # 256 classes: >= 32 per rank up to 8 ranks; the narrow split takes <= 8 bits
+            fine_bits = 8
         if (1 << fine_bits) < self.world or owner_shift + fine_bits > 64:
             raise ValueError("need at least one owner class per rank inside the 64 payload bits")
         self.fine_bits = fine_bits
@@ -68,143 +91,166 @@ class ShardedJoin:
         self.balance = balance               # False: equal-width class ranges (a static radix map)
         self.cuts = [self.nclasses * r // self.world for r in range(self.world + 1)]
         self.local_opts = local_opts
-        self.staged_local_join = True        # False: one rhj_join_dev call after both exchanges (no S-transfer overlap)
+        self.narrow = narrow                 # False: always exchange 16-byte tuples
+        self.bind_stream = bind_stream       # the engine launches on torch's current stream (no fences needed)
         self.collect_timings = False         # True: sum the engine's per-kernel HIP-event timings over the calls of a join
+        #                                      (synchronises after every engine call: for profiling steps, not timed ones)
         self.kernel_ms = {}
         self.stats = {}
+        self._bound = None
 
     def owner_of(self, payload):
         """rank that owns the join values `payload` (numpy uint64 array) under the class ranges of the last join"""
-        import numpy as np
         cls = ((payload >> np.uint64(self.owner_shift)) & np.uint64(self.nclasses - 1)).astype(np.int64)
         return np.searchsorted(np.asarray(self.cuts[1:], dtype=np.int64), cls, side="right")
 
-    # -- step 1: class split of one shard (compute) -------------------------------------------------
-    def split(self, rel, n):
-        """One scatter-partition pass by owner class.  Returns (staged [n,2] tensor with each class's tuples
-        contiguous, in class order; the shard's class histogram as an int64 tensor of nclasses)."""
-        dev = rel.device
-        staged = torch.empty((max(n, 1), 2), dtype=torch.int64, device=dev)
-        bounds = torch.empty(self.nclasses + 1, dtype=torch.int64, device=dev)
-        self._fence_torch(dev)                    # rel / buffers produced by torch ops are complete
-        self.engine.partition_at(rel, n, self.owner_shift, self.fine_bits, staged, bounds)
-        self._fence_engine()                      # staged / bounds complete before torch and RCCL touch them
-        return staged, (bounds[1:] - bounds[:-1]).contiguous()
+    # ------------------------------------------------------------------------------------------------
+    def join(self, R, nR, S, nS, out=None):
+        """Local shards in ([n,2] int64 tensors of {rowID, payload}), local share of the result out:
+        (count, [count,2] tensor of {rowR,rowS}, global rowIDs)."""
+        dev = R.device
+        self._bind(dev)
+        if self.world == 1:
+            return self._local_join_whole(R, nR, S, nS, out)
+        eng = self.engine
+        can_narrow = self.narrow and hasattr(eng, "shard_stats") and self.world <= MAX_NARROW_WORLD
+        if can_narrow:
+            self._fence_torch(dev)                     # (fences are no-ops once the engine shares torch's stream, see _bind)
+            histR, minR, maxR = eng.shard_stats(0, R, nR, self.owner_shift, self.fine_bits)
+            self._collect()
+            histS, minS, maxS = eng.shard_stats(1, S, nS, self.owner_shift, self.fine_bits)
+            self._collect()
+        else:
+            histR, histS = self._class_histogram(R, nR), self._class_histogram(S, nS)
+            minR = maxR = minS = maxS = 0
+        meta = self._gather_meta([nR, nS, _i64(minR), _i64(maxR), _i64(minS), _i64(maxS), 1 if can_narrow else 0], histR, histS)
+        (inR, outR), (inS, outS) = self._plan_exchange(meta)
+        mR, mS = sum(outR), sum(outS)
+        self.stats = {"recv_R": mR, "recv_S": mS, "cuts": list(self.cuts), "format": "tuple16"}
+        # one decision for all ranks, from gathered numbers only
+        spanok = all(_u64(meta["head"][r][3]) - _u64(meta["head"][r][2]) < (1 << 32) and
+                     _u64(meta["head"][r][5]) - _u64(meta["head"][r][4]) < (1 << 32) for r in range(self.world))
+        narrow = all(meta["head"][r][6] for r in range(self.world)) and spanok
+        plan = None
+        if narrow:
+            from .binding import shard_plan
+            ok, plan = shard_plan(max(meta["recvR"]), max(meta["recvS"]), self.local_opts)
+            narrow = ok and min(meta["recvR"]) >= 0
+        if not narrow:
+            return self._join_tuple16(R, nR, S, nS, inR, outR, inS, outS, out)
 
-    def class_histogram(self, rel, n):
-        """The shard's class histogram alone (rhj_histogram at the owner bits): int64 tensor of nclasses."""
+        from .binding import narrow_bytes, narrow_key_offset
+        self.stats["format"] = "narrow12"
+        self.stats["kept_local"] = inR[self.rank] + inS[self.rank]
+        self.stats["exchange_bytes_sent"] = 12 * ((nR - inR[self.rank]) + (nS - inS[self.rank]))
+        self.stats["plan"] = (plan.passes, plan.bits1, plan.bits2)
+
+        def split_and_send(side, rel, n, key_base, in_splits, out_splits):
+            buf = torch.empty(max(narrow_bytes(n), 16), dtype=torch.uint8, device=dev)
+            self._fence_torch(dev)
+            eng.shard_split(side, rel, n, self.owner_shift, self.fine_bits, key_base, buf)
+            self._fence_engine()
+            koff = narrow_key_offset(n)
+            P = buf[:8 * n].view(torch.int64)
+            K = buf[koff:koff + 4 * n].view(torch.int32)
+            m = sum(out_splits)
+            rP = torch.empty(max(m, 1), dtype=torch.int64, device=dev)
+            rK = torch.empty(max(m, 1), dtype=torch.int32, device=dev)
+            w1 = self._a2a(rP[:m], P, out_splits, in_splits, async_op=True)
+            w2 = self._a2a(rK[:m], K, out_splits, in_splits, async_op=True)
+            return rP, rK, m, (w1, w2), buf          # buf must stay alive until the transfer has finished
+
+        hR = split_and_send(0, R, nR, _u64(meta["head"][self.rank][2]), inR, outR)      # R on the wire ...
+        hS = split_and_send(1, S, nS, _u64(meta["head"][self.rank][4]), inS, outS)      # ... while S is being split
+
+        def seg_offsets(out_splits):
+            off = [0]
+            for c in out_splits:
+                off.append(off[-1] + c)
+            return off
+
+        for w in hR[3]:
+            if w is not None:
+                w.wait()                               # (stream-level wait: the host runs on)
+        self._fence_torch(dev)
+        eng.shard_partition(0, hR[0], hR[1], mR, seg_offsets(outR), plan)      # R's local passes overlap the S transfer
+        self._collect()
+        for w in hS[3]:
+            if w is not None:
+                w.wait()
+        self._fence_torch(dev)
+        eng.shard_partition(1, hS[0], hS[1], mS, seg_offsets(outS), plan)
+        self._collect()
+        row0R = [_u64(meta["head"][r][2]) for r in range(self.world)]
+        row0S = [_u64(meta["head"][r][4]) for r in range(self.world)]
+        cap = out.shape[0] if out is not None else max(mR, mS) + 1024
+        if out is None:
+            out = torch.empty((cap, 2), dtype=torch.int64, device=dev)
+        cnt = eng.shard_join(row0R, row0S, out, cap, allow_overflow=True)
+        if cnt > cap:                                  # more pairs than guessed: the exact size is known now
+            out = torch.empty((cnt, 2), dtype=torch.int64, device=dev)
+            cnt = eng.shard_join(row0R, row0S, out, cnt)
+        self._collect()
+        return cnt, out
+
+    # -- fallback: 16-byte tuples on the wire ------------------------------------------------------------
+    def _join_tuple16(self, R, nR, S, nS, inR, outR, inS, outS, out):
+        eng, dev = self.engine, R.device
+        self.stats["exchange_bytes_sent"] = 16 * ((nR - inR[self.rank]) + (nS - inS[self.rank]))
+
+        def split_and_send(rel, n, in_splits, out_splits):
+            staged = torch.empty((max(n, 1), 2), dtype=torch.int64, device=dev)
+            bounds = torch.empty(self.nclasses + 1, dtype=torch.int64, device=dev)
+            self._fence_torch(dev)
+            eng.partition_at(rel, n, self.owner_shift, self.fine_bits, staged, bounds)
+            self._fence_engine()
+            m = sum(out_splits)
+            recv = torch.empty((max(m, 1), 2), dtype=torch.int64, device=dev)
+            work = self._a2a(recv[:m], staged[:n], out_splits, in_splits, async_op=True)
+            return recv, m, work, staged
+
+        hR = split_and_send(R, nR, inR, outR)
+        hS = split_and_send(S, nS, inS, outS)
+        for h in (hR, hS):
+            if h[2] is not None:
+                h[2].wait()
+        return self._local_join_whole(hR[0], hR[1], hS[0], hS[1], out)
+
+    def _class_histogram(self, rel, n):
         hist = torch.empty(self.nclasses, dtype=torch.int64, device=rel.device)
         self._fence_torch(rel.device)
         self.engine.histogram(rel, n, self.owner_shift, self.fine_bits, hist)
         self._fence_engine()
-        return hist
+        return hist.cpu().numpy()
 
-    # -- step 2: count matrix -> class ranges and exchange sizes -----------------------------------
-    def plan_exchange(self, histR, histS):
-        """all_gather of this rank's (2 x C) class histogram.  Sets self.cuts; returns, per relation,
-        (in_splits, out_splits): tuples this rank sends to / receives from every rank."""
-        mine = torch.stack([histR, histS])                                   # [2, C]
-        via_host = mine.is_cuda and dist.get_backend(self.group) == "gloo"   # rehearsal: several ranks on one GPU
-        if via_host:
-            mine = mine.cpu()
-        mine = mine.reshape(-1).contiguous()
-        allh = torch.empty(self.world * mine.numel(), dtype=mine.dtype, device=mine.device)
-        dist.all_gather_into_tensor(allh, mine, group=self.group)
-        allh = allh.cpu().view(self.world, 2, self.nclasses)                 # host sync: sizes must be known
+    # -- step 2: count matrix -> class ranges and exchange sizes -----------------------------------------
+    def _gather_meta(self, head, histR, histS):
+        """ONE all_gather of this rank's {head words, 2 x C class counts}; returns the gathered numbers (host)."""
+        mine = torch.tensor(list(head) + [int(x) for x in histR] + [int(x) for x in histS], dtype=torch.int64)
+        on_dev = dist.get_backend(self.group) == "nccl"
+        if on_dev:
+            mine = mine.to(torch.device("cuda", torch.cuda.current_device()))
+        allv = torch.empty(self.world * mine.numel(), dtype=torch.int64, device=mine.device)
+        dist.all_gather_into_tensor(allv, mine, group=self.group)
+        allv = allv.cpu().view(self.world, -1)                               # host sync: sizes must be known
+        nh, C = len(head), self.nclasses
+        return {"head": [[int(x) for x in allv[r, :nh]] for r in range(self.world)],
+                "hist": allv[:, nh:].reshape(self.world, 2, C)}
+
+    def _plan_exchange(self, meta):
+        """Sets self.cuts; returns, per relation, (in_splits, out_splits): tuples this rank sends to / receives from every
+        rank; meta gets "recvR" / "recvS": what EVERY rank receives (the same lists on all ranks)."""
+        allh = meta["hist"]
         if self.balance:
             self.cuts = balanced_cuts(allh.sum(dim=(0, 1)).tolist(), self.world)
-        lo, hi = self.cuts[self.rank], self.cuts[self.rank + 1]
+        cuts = self.cuts
         splits = []
         for rel in (0, 1):
-            send = [int(allh[self.rank, rel, self.cuts[d]:self.cuts[d + 1]].sum()) for d in range(self.world)]
-            recv = [int(allh[src, rel, lo:hi].sum()) for src in range(self.world)]
+            send = [int(allh[self.rank, rel, cuts[d]:cuts[d + 1]].sum()) for d in range(self.world)]
+            recv = [int(allh[src, rel, cuts[self.rank]:cuts[self.rank + 1]].sum()) for src in range(self.world)]
             splits.append((send, recv))
+            meta["recvR" if rel == 0 else "recvS"] = [int(allh[:, rel, cuts[d]:cuts[d + 1]].sum()) for d in range(self.world)]
         return splits
-
-    # -- step 3: tuple exchange (communication) ----------------------------------------------------
-    def start_exchange(self, staged, n, in_splits, out_splits):
-        """Launches the all-to-all of `staged`; returns a handle for finish_exchange.  With RCCL the
-        transfer proceeds on the communicator's stream while the caller keeps launching kernels."""
-        m = int(sum(out_splits))
-        recv = torch.empty((max(m, 1), 2), dtype=torch.int64, device=staged.device)
-        work = self._a2a(recv[:m], staged[:n], out_splits, in_splits, async_op=True)
-        return recv, m, work, staged              # staged must stay alive until the transfer has finished
-
-    @staticmethod
-    def finish_exchange(handle):
-        recv, m, work, _staged = handle
-        if work is not None:
-            work.wait()
-        return recv, m
-
-    def join(self, R, nR, S, nS, out=None):
-        """Local shards in, local share of the result out: (count, [count,2] tensor of {rowR,rowS}).
-
-        Schedule (communication on the RCCL stream, kernels on the engine's stream):
-            class histogram of S | split R | count matrix | exchange R  ||  split S | exchange S  ||  partition received R |
-            partition received S | bucket join
-        i.e. the R transfer overlaps the class split of S and the S transfer the local radix partitioning of R (stage
-        entry points rhj_histogram / rhj_partition_at / rhj_partition / rhj_bucket_join of the C-ABI).  The class ranges
-        need the histogram of BOTH relations (the skewed one is usually S), hence the cheap histogram-only pass over S
-        first (8 B/tuple algorithmic against 40 for the split)."""
-        if self.world == 1:
-            return self._local_join_whole(R, nR, S, nS, out)
-        if hasattr(self.engine, "histogram"):
-            hS_ = self.class_histogram(S, nS)
-            stagedR, hR_ = self.split(R, nR)
-            (inR, outR), (inS, outS) = self.plan_exchange(hR_, hS_)
-            hR = self.start_exchange(stagedR, nR, inR, outR)   # R on the wire ...
-            stagedS, _ = self.split(S, nS)                     # ... while S is being split
-            hS = self.start_exchange(stagedS, nS, inS, outS)
-        else:
-            stagedR, hR_ = self.split(R, nR)
-            stagedS, hS_ = self.split(S, nS)
-            (inR, outR), (inS, outS) = self.plan_exchange(hR_, hS_)
-            hR = self.start_exchange(stagedR, nR, inR, outR)   # both relations on the wire ...
-            hS = self.start_exchange(stagedS, nS, inS, outS)
-        mR, mS = hR[1], hS[1]
-        self.stats = {"recv_R": mR, "recv_S": mS, "cuts": list(self.cuts)}
-        if not self.staged_local_join or not hasattr(self.engine, "partition"):
-            Rx, _ = self.finish_exchange(hR)
-            Sx, _ = self.finish_exchange(hS)
-            return self._local_join_whole(Rx, mR, Sx, mS, out)
-        plan = self._plan(mR, mS)
-        dev = R.device
-        Rx, _ = self.finish_exchange(hR)
-        hR = stagedR = None                                    # the send buffer of R can be recycled now
-        if plan.passes == 0 or mR == 0 or mS == 0:
-            Sx, _ = self.finish_exchange(hS)
-            return self._local_join_whole(Rx, mR, Sx, mS, out)
-        b1, b2 = plan.bits1, (plan.bits2 if plan.passes == 2 else 0)
-        nparts = 1 << (b1 + b2)
-        partR = torch.empty((max(mR, 1), 2), dtype=torch.int64, device=dev)
-        psR = torch.empty(nparts + 1, dtype=torch.int64, device=dev)
-        self._fence_torch(dev)                                 # R has landed; S is still in flight
-        self.engine.partition(Rx, mR, b1, b2, partR, psR)      # local radix passes over R overlap the S transfer
-        self._collect()
-        Sx, _ = self.finish_exchange(hS)
-        hS = stagedS = None
-        partS = torch.empty((max(mS, 1), 2), dtype=torch.int64, device=dev)
-        psS = torch.empty(nparts + 1, dtype=torch.int64, device=dev)
-        self._fence_torch(dev)
-        self.engine.partition(Sx, mS, b1, b2, partS, psS)
-        self._collect()
-        cap = out.shape[0] if out is not None else max(mR, mS) + 1024
-        if out is None:
-            out = torch.empty((cap, 2), dtype=torch.int64, device=dev)
-        self._fence_torch(dev)
-        cnt = self.engine.bucket_join(partR, psR, partS, psS, nparts, b1 + b2, out, cap,
-                                      probe_split=plan.probe_split, allow_overflow=True)
-        if cnt > cap:
-            out = torch.empty((cnt, 2), dtype=torch.int64, device=dev)
-            self._fence_torch(dev)
-            cnt = self.engine.bucket_join(partR, psR, partS, psS, nparts, b1 + b2, out, cnt, probe_split=plan.probe_split)
-        self._collect()
-        return cnt, out
-
-    def _plan(self, mR, mS):
-        from .binding import plan as resolve
-        return resolve(mR, mS, self.local_opts)
 
     def _local_join_whole(self, Rx, mR, Sx, mS, out):
         cap = out.shape[0] if out is not None else max(mR, mS) + 1024
@@ -218,16 +264,29 @@ class ShardedJoin:
         self._collect()
         return cnt, out
 
-    # The engine launches on its own HIP stream unless it was given torch's (rhj_set_stream); these two
-    # host-side fences make the hand-offs correct either way.  They cost microseconds per join.
+    # -- ordering ------------------------------------------------------------------------------------------
+    def _bind(self, dev):
+        """Put the engine on torch's current stream: torch ops, RCCL hand-offs (work.wait()) and the engine's kernels are
+        then ordered by the stream itself and the path has no host-side fence."""
+        if dev.type != "cuda" or not self.bind_stream or not hasattr(self.engine, "set_stream"):
+            return
+        cur = torch.cuda.current_stream(dev).cuda_stream
+        if cur == 0:                     # torch's default stream has no handle to hand over: the engine keeps its own stream
+            self._bound = None           # and the hand-offs are fenced on the host (tests; bench.py sets a real stream)
+            return
+        if self._bound != cur:
+            self.engine.set_stream(cur)
+            self._bound = cur
+
     def _fence_torch(self, dev):
-        if dev.type == "cuda":
+        if dev.type == "cuda" and self._bound is None:
             torch.cuda.current_stream(dev).synchronize()
 
     def _fence_engine(self):
-        sync = getattr(self.engine, "sync", None)
-        if sync is not None:
-            sync()
+        if self._bound is None:
+            sync = getattr(self.engine, "sync", None)
+            if sync is not None:
+                sync()
         self._collect()
 
     def _collect(self):
@@ -249,3 +308,8 @@ class ShardedJoin:
             out.copy_(h_out)
             return None
         return dist.all_to_all_single(out, inp, out_splits, in_splits, group=self.group, async_op=async_op)
+
+    def transport(self):
+        """what moves the tuples: for bench.py's config.exchange"""
+        b = dist.get_backend(self.group)
+        return "RCCL all-to-all over xGMI" if b == "nccl" else f"{b} all-to-all staged through host memory (single-GPU rehearsal)"

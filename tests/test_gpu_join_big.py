@@ -227,3 +227,53 @@ def test_one_billion_count_and_checksum(engine, kind, plan, narrow):
     for b in (dR, dS, dO):
         b.free()
     engine.release_workspace()
+
+
+def test_wide_rowid_fallback_is_per_join(oracle):
+    """A rowID >= 2^32 makes ONE join repeat itself in the 16-byte format (the histogram kernel reports it before any
+    scatter has run); the next join on the same context is narrow again -- nothing sticks to the context."""
+    e = Engine(0)
+    try:
+        e.set_option("join.big_tables", 1)
+        e.set_option("join.big_kernel", CT)
+        e.set_option("partition.narrow", 2)       # (inputs this small are not narrow by default); set ONCE, never re-armed below
+        rng = np.random.default_rng(3)
+        rv = rng.permutation(1 << 22)[:40_000].astype(np.uint64)
+        R = rel(rng, 40_000, few_partitions(rv, 2))
+        S = rel(rng, 30_000, R["payload"][rng.integers(0, 40_000, 30_000)], key0=1 << 20)
+        exp = sorted_pairs(oracle.join(R, S))
+        for wide in (False, True, False, True, True, False):
+            Sx = S.copy()
+            if wide:
+                Sx["key"][123] = (1 << 40) + 5
+            got = e.join(R, Sx, opts=Opts(2, 8, 8))
+            assert e.info("last.narrow") == (0 if wide else 2)
+            assert np.array_equal(sorted_pairs(got), sorted_pairs(oracle.join(R, Sx)) if wide else exp)
+    finally:
+        e.close()
+
+
+def test_bucket_join_checks_its_radix_bits_contract(engine):
+    """rhj_bucket_join routes 16-bit plans with large partitions to the compact-table kernel, which compares only
+    payload >> radix_bits: partitions whose payloads do NOT share those low bits are refused, not joined wrongly."""
+    from radixhashjoin_amd.binding import RhjError
+    n = 40_000
+    rng = np.random.default_rng(9)
+    t = np.empty(n, dtype=TUPLE)
+    t["key"] = np.arange(n, dtype=np.uint64)
+    t["payload"] = rng.integers(0, 1 << 40, n).astype(np.uint64)             # low 16 bits differ inside the one "partition"
+    d = engine.to_device(t)
+    st = engine.to_device(np.array([0, n], dtype=np.uint64))
+    out = engine.alloc(16 * 4 * n)
+    engine.set_option("join.big_tables", 1)
+    try:
+        with pytest.raises(RhjError, match="radix_bits"):
+            engine.bucket_join(d, st, d, st, 1, 16, out, 4 * n)
+        # with the true number of constant bits (none) the same call is a correct self-join on the payloads
+        engine.set_option("join.big_tables", -1)
+        cnt = engine.bucket_join(d, st, d, st, 1, 0, out, 4 * n)
+        assert cnt >= n
+    finally:
+        engine.set_option("join.big_tables", -1)
+    for x in (d, st, out):
+        x.free()

@@ -1,0 +1,148 @@
+"""GPU suite: the multi-GPU stage entry points of include/rhj.h (rhj_shard_stats / _split / _partition / _join) in ONE
+process: `world` ranks are emulated by running the sender calls once per shard, doing the all-to-all with numpy slices on
+the host, and running the receiver calls once per owner -- every kernel an 8-GPU job runs (class histogram with rowID range,
+class split into the 12-byte wire format, segmented fused two-pass partition with sender tags, tagged bucket joins) against
+the CPU oracle's join of the GLOBAL relations.  RowIDs are global and exceed 2^32 (the tags must resolve them); the real
+collectives are covered by tests/test_gpu_sharded.py and tests/test_sharded_gloo.py."""
+import numpy as np
+import pytest
+
+from oracle.pyoracle import TUPLE
+from radixhashjoin_amd import Engine, Opts
+from radixhashjoin_amd.binding import narrow_bytes, narrow_key_offset, shard_plan
+from radixhashjoin_amd.sharded import balanced_cuts
+
+pytestmark = pytest.mark.gpu
+SHIFT, BITS = 20, 8
+BKT, CT, CT_HALF = 0, 2, 3
+
+
+def few_partitions(values, nlow):
+    """payload = join value << 16 | one of `nlow` 16-bit patterns chosen by the value: large partitions under a 16-bit plan"""
+    lows = np.random.default_rng(nlow).permutation(1 << 16)[:nlow].astype(np.uint64)
+    return (values << np.uint64(16)) | lows[(values % np.uint64(nlow)).astype(np.int64)]
+
+
+def sharded_join(eng, shardsR, shardsS, plan):
+    """the schedule of radixhashjoin_amd/sharded.py with the collectives replaced by host slicing; returns all pairs"""
+    world = len(shardsR)
+    C = 1 << BITS
+    sent = {0: [], 1: []}                # per side: per sender (payloads sorted by class, local rowIDs, class histogram, base)
+    for side, shards in ((0, shardsR), (1, shardsS)):
+        for t in shards:
+            n = len(t)
+            d = eng.to_device(t)
+            hist, kmin, kmax = eng.shard_stats(side, d, n, SHIFT, BITS)
+            dig = ((t["payload"] >> np.uint64(SHIFT)) & np.uint64(C - 1)).astype(np.int64)
+            assert np.array_equal(hist, np.bincount(dig, minlength=C))
+            assert (kmin, kmax) == (int(t["key"].min()), int(t["key"].max()))
+            buf = eng.alloc(max(narrow_bytes(n), 16))
+            starts = eng.alloc(8 * (C + 1))
+            eng.shard_split(side, d, n, SHIFT, BITS, kmin, buf, starts)
+            raw = buf.to_numpy(np.uint8, narrow_bytes(n))
+            P = raw[:8 * n].view(np.uint64).copy()
+            K = raw[narrow_key_offset(n):narrow_key_offset(n) + 4 * n].view(np.uint32).copy()
+            st = starts.to_numpy(np.uint64, C + 1)
+            assert np.array_equal(st, np.concatenate([[0], np.cumsum(hist)]).astype(np.uint64))
+            # the split is a stable-enough class partition of exactly the shard's tuples, rowIDs local to the shard
+            for c in (0, C // 2, C - 1):
+                seg = slice(int(st[c]), int(st[c + 1]))
+                assert np.all(((P[seg] >> np.uint64(SHIFT)) & np.uint64(C - 1)) == c)
+            a = np.sort(np.stack([P, K.astype(np.uint64) + np.uint64(kmin)], axis=1).view([("p", "<u8"), ("k", "<u8")]).ravel(), order=["k"])
+            b = np.sort(np.stack([t["payload"], t["key"]], axis=1).view([("p", "<u8"), ("k", "<u8")]).ravel(), order=["k"])
+            assert np.array_equal(a, b)
+            sent[side].append((P, K, st, kmin))
+            for x in (d, buf, starts):
+                x.free()
+    total = np.zeros(C, dtype=np.int64)
+    for side in (0, 1):
+        for (_, _, st, _) in sent[side]:
+            total += np.diff(st.astype(np.int64))
+    cuts = balanced_cuts(total.tolist(), world)
+    pairs = []
+    for owner in range(world):
+        lo, hi = cuts[owner], cuts[owner + 1]
+        for side in (0, 1):
+            Ps, Ks, off = [], [], [0]
+            for (P, K, st, _) in sent[side]:
+                a, b = int(st[lo]), int(st[hi])
+                Ps.append(P[a:b]); Ks.append(K[a:b]); off.append(off[-1] + b - a)
+            m = off[-1]
+            dP = eng.to_device(np.concatenate(Ps) if m else np.zeros(1, dtype=np.uint64))
+            dK = eng.to_device(np.concatenate(Ks) if m else np.zeros(1, dtype=np.uint32))
+            eng.shard_partition(side, dP, dK, m, off, plan)
+            eng.sync()
+            dP.free(); dK.free()
+        row0R = [x[3] for x in sent[0]]
+        row0S = [x[3] for x in sent[1]]
+        cnt = eng.shard_join(row0R, row0S, None, 0)                         # count only
+        out = eng.alloc(16 * max(cnt, 1))
+        assert eng.shard_join(row0R, row0S, out, cnt) == cnt
+        pairs.append(out.to_numpy(np.uint64, 2 * cnt).reshape(-1, 2))
+        out.free()
+    return np.concatenate(pairs)
+
+
+def global_relations(rng, world, n_per, nlow, dup):
+    """R, S as lists of shards; rowIDs global, shard r's in [r * 5 * 2^30, ...): beyond 2^32 from rank 1 on"""
+    nglob = n_per * world
+    vals = rng.permutation(1 << 24)[:max(nglob // dup, 1)].astype(np.uint64)
+    rv = vals[rng.integers(0, len(vals), nglob)] if dup > 1 else vals[:nglob]
+    sv = vals[rng.integers(0, len(vals), nglob)]
+    sv[::53] ^= np.uint64(1 << 45)                                            # some foreign keys match nothing
+    def shards(v):
+        out = []
+        for r in range(world):
+            t = np.empty(n_per, dtype=TUPLE)
+            t["key"] = rng.permutation(n_per).astype(np.uint64) + np.uint64(r * 5 * (1 << 30) + 12345)
+            pv = v[r * n_per:(r + 1) * n_per]
+            t["payload"] = few_partitions(pv, nlow) if nlow else pv * np.uint64(0x9E3779B97F4A7C15)
+            out.append(t)
+        return out
+    return shards(rv), shards(sv)
+
+
+@pytest.mark.parametrize("world,n_per,nlow,dup,plan,kernel", [
+    (3, 60_000, 0, 1, Opts(2, 4, 4), BKT),           # one-table kernel, tagged; 3 ranks
+    (2, 50_000, 0, 3, Opts(2, 5, 3), BKT),           # duplicates on both sides
+    (8, 20_000, 4, 1, Opts(2, 8, 8), CT),            # compact-table kernel, 8 ranks, 40 K-tuple partitions (chunks, split tasks)
+    (4, 30_000, 12, 2, Opts(2, 8, 8), CT),           # duplicates: the generic (wavefront, slot) loop with tags
+    (2, 40_000, 9, 1, Opts(2, 8, 8), CT_HALF),       # half-size compact table
+    (5, 9_000, 3, 1, Opts(2, 8, 8), CT),
+])
+def test_shard_stage_calls_equal_global_join(oracle, world, n_per, nlow, dup, plan, kernel):
+    rng = np.random.default_rng(world * 1000 + n_per)
+    Rs, Ss = global_relations(rng, world, n_per, nlow, dup)
+    ok, rplan = shard_plan(n_per, n_per, plan)
+    assert ok == 1 or ok is True
+    eng = Engine(0)
+    try:
+        if kernel != BKT:
+            eng.set_option("join.big_tables", 1)
+            eng.set_option("join.big_kernel", kernel)
+        got = sharded_join(eng, Rs, Ss, rplan)
+        assert eng.info("last.join_kernel") == kernel
+    finally:
+        eng.close()
+    exp = oracle.join(np.concatenate(Rs), np.concatenate(Ss))
+    assert len(got) == len(exp)
+    a = got[np.lexsort((got[:, 1], got[:, 0]))]
+    e = np.stack([exp["keyR"], exp["keyS"]], axis=1)
+    e = e[np.lexsort((e[:, 1], e[:, 0]))]
+    assert np.array_equal(a, e)
+    assert got[:, 0].max() >= (1 << 32)                                     # the tags really had to resolve wide rowIDs
+
+
+def test_shard_split_refuses_a_base_that_does_not_fit(engine):
+    t = np.zeros(2000, dtype=TUPLE)
+    t["key"] = np.arange(2000, dtype=np.uint64) * np.uint64(1 << 22)         # span 2^33
+    d = engine.to_device(t)
+    _, kmin, kmax = engine.shard_stats(0, d, len(t), SHIFT, BITS)
+    assert kmax - kmin >= (1 << 32)
+    buf = engine.alloc(narrow_bytes(len(t)))
+    from radixhashjoin_amd.binding import RhjError
+    with pytest.raises(RhjError):
+        engine.shard_split(0, d, len(t), SHIFT, BITS, kmin, buf)
+    with pytest.raises(RhjError):
+        engine.shard_split(0, d, len(t), SHIFT, BITS, kmin + 1, buf)          # base above the smallest rowID
+    d.free(); buf.free()

@@ -2,9 +2,10 @@
 
 A gpurun box has one MI355X, so world_size 2 (and 3: class ranges need no power of two) run as ranks that share
 cuda:0, with gloo moving the exchange through the host (RHJ_BENCH_BACKEND=gloo does the same for bench.py).  Everything
-except the transport is what an 8-GPU job runs: rhj_partition_at class split, count matrix, uneven
-all_to_all_single, rhj_partition of what arrived, rhj_bucket_join, sharded result.  The union of the ranks' pair sets
-must equal the CPU oracle's join of the global relations."""
+except the transport is what an 8-GPU job runs: rhj_shard_stats, count matrix, rhj_shard_split into the 12-byte wire
+format, uneven all_to_all_single of payloads and rowIDs, rhj_shard_partition of what arrived, rhj_shard_join (cases with a
+two-pass local plan), or the 16-byte fallback rhj_partition_at / all-to-all / rhj_join_dev (the others).  The union of the
+ranks' pair sets must equal the CPU oracle's join of the global relations."""
 import os
 import socket
 import sys
@@ -44,7 +45,7 @@ def worker(rank, world, port, n_per_rank, D, zipf, opts, q):
     pairs = out[:cnt].cpu().numpy().view(np.uint64)
     shards = [None] * world
     dist.all_gather_object(shards, (R.cpu().numpy().view(np.uint64), S.cpu().numpy().view(np.uint64), pairs,
-                                    sj.stats["recv_R"] + sj.stats["recv_S"]))
+                                    sj.stats["recv_R"] + sj.stats["recv_S"], sj.stats["format"]))
     if rank == 0:
         o = Oracle()
         def tup(parts):
@@ -60,7 +61,7 @@ def worker(rank, world, port, n_per_rank, D, zipf, opts, q):
         e = np.stack([exp["keyR"], exp["keyS"]], axis=1)
         e = e[np.lexsort((e[:, 1], e[:, 0]))]
         recv = [s[3] for s in shards]
-        q.put((len(allp), len(exp), bool(np.array_equal(a, e)), max(recv) / (sum(recv) / world)))
+        q.put((len(allp), len(exp), bool(np.array_equal(a, e)), max(recv) / (sum(recv) / world), shards[0][4]))
     dist.barrier()
     eng.close()
     dist.destroy_process_group()
@@ -74,20 +75,24 @@ def free_port():
     return p
 
 
-@pytest.mark.parametrize("world,n_per_rank,D,zipf,opts", [(2, 1_500_000, 3_000_000, 0, None),       # PK/FK, automatic local plan
-                                                          (2, 400_000, 100_000, 0, (2, 4, 4)),      # duplicates, forced two-pass plan
-                                                          (3, 300_000, 900_000, 1250, None)])       # skew, 3 ranks
-def test_sharded_join_real_engine(world, n_per_rank, D, zipf, opts):
+@pytest.mark.parametrize("world,n_per_rank,D,zipf,opts,fmt", [
+    (2, 1_500_000, 3_000_000, 0, None, "tuple16"),           # PK/FK, automatic local plan (one pass: 16-byte fallback)
+    (2, 400_000, 100_000, 0, (2, 4, 4), "narrow12"),         # duplicates, forced two-pass plan: 12-byte wire format
+    (3, 300_000, 900_000, 1250, None, "tuple16"),            # skew, 3 ranks
+    (3, 500_000, 1_500_000, 1250, (2, 6, 6), "narrow12"),    # skew, 3 ranks, narrow
+    (2, 3_000_000, 6_000_000, 0, (2, 8, 8), "narrow12")])    # the 8+8 plan of the large configurations
+def test_sharded_join_real_engine(world, n_per_rank, D, zipf, opts, fmt):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = free_port()
     procs = [ctx.Process(target=worker, args=(r, world, port, n_per_rank, D, zipf, opts, q)) for r in range(world)]
     for p in procs:
         p.start()
-    got, exp, same, imbalance = q.get(timeout=600)
+    got, exp, same, imbalance, used = q.get(timeout=600)
     for p in procs:
         p.join(timeout=120)
         assert p.exitcode == 0
     assert got == exp and same
+    assert used == fmt
     if zipf:
         assert imbalance <= 1.3, imbalance

@@ -59,6 +59,48 @@ class OracleEngine:
                 assert len(np.unique(seg)) <= 1
         return self.join_dev(d_Rp, nR, d_Sp, nS, d_out, capacity)
 
+    # ---- the narrow wire format (include/rhj.h "multi-GPU stage entry points"), restated with numpy ----------------
+    def shard_stats(self, side, d_rel, n, shift, bits):
+        a = self._np(d_rel, n).view(np.uint64)
+        dig = ((a[:, 1] >> np.uint64(shift)) & np.uint64((1 << bits) - 1)).astype(np.int64)
+        self._dig = getattr(self, "_dig", {})
+        self._dig[side] = dig
+        return (np.bincount(dig, minlength=1 << bits).astype(np.int64), int(a[:, 0].min()) if n else 0,
+                int(a[:, 0].max()) if n else 0)
+
+    def shard_split(self, side, d_rel, n, shift, bits, key_base, d_narrow_out, d_class_start=None):
+        from radixhashjoin_amd.binding import narrow_key_offset
+        a = self._np(d_rel, n).view(np.uint64)
+        order = np.argsort(self._dig[side], kind="stable")
+        local = a[order, 0] - np.uint64(key_base)
+        assert np.all(local < np.uint64(1 << 32))
+        buf = d_narrow_out.numpy()
+        buf[:8 * n] = a[order, 1].view(np.uint8)
+        koff = narrow_key_offset(n)
+        buf[koff:koff + 4 * n] = local.astype(np.uint32).view(np.uint8)
+
+    def shard_partition(self, side, d_payloads, d_rowids, m, seg_off, plan):
+        assert plan.passes == 2 and seg_off[0] == 0 and seg_off[-1] == m
+        sender = np.repeat(np.arange(len(seg_off) - 1), np.diff(np.asarray(seg_off, dtype=np.int64)))
+        self._recv = getattr(self, "_recv", {})
+        self._recv[side] = (d_payloads.numpy()[:m].view(np.uint64).copy(), d_rowids.numpy()[:m].view(np.uint32).copy(), sender)
+
+    def shard_join(self, row0_R, row0_S, d_out=None, capacity=0, allow_overflow=False):
+        from oracle.pyoracle import TUPLE
+        rel = []
+        for side, row0 in ((0, row0_R), (1, row0_S)):
+            P, K, sender = self._recv[side]
+            t = np.empty(len(P), dtype=TUPLE)
+            t["payload"] = P
+            t["key"] = np.asarray(row0, dtype=np.uint64)[sender] + K.astype(np.uint64)       # global rowID = sender's base + local
+            rel.append(t)
+        p = self.o.join(rel[0], rel[1])
+        k = min(len(p), capacity)
+        if d_out is not None and k:
+            d_out.numpy()[:k, 0] = p["keyR"][:k].view(np.int64)
+            d_out.numpy()[:k, 1] = p["keyS"][:k].view(np.int64)
+        return len(p)
+
     def join_dev(self, d_R, nR, d_S, nS, d_out=None, capacity=0, opts=None, allow_overflow=False):
         from oracle.pyoracle import TUPLE
         R = np.ascontiguousarray(self._np(d_R, nR)).view(np.uint64).reshape(-1, 2)
@@ -84,7 +126,7 @@ def zipf_payloads(o, n, D, theta, seed):
     return lut[r]
 
 
-def worker(rank, world, port, n_per_rank, dup, staged, q, zipf=None, balance=True):
+def worker(rank, world, port, n_per_rank, dup, narrow, q, zipf=None, balance=True):
     sys.path.insert(0, ROOT)
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
@@ -104,9 +146,15 @@ def worker(rank, world, port, n_per_rank, dup, staged, q, zipf=None, balance=Tru
         a[:, 0], a[:, 1] = t["key"][lo:hi], t["payload"][lo:hi]
         return torch.from_numpy(a.view(np.int64))
 
-    sj = ShardedJoin(OracleEngine(), dist.group.WORLD, balance=balance)
-    sj.staged_local_join = staged
+    # narrow: the 12-byte wire format (needs a two-pass local plan: forced here, the sizes are tiny); else 16-byte tuples
+    from radixhashjoin_amd import Opts
+    sj = ShardedJoin(OracleEngine(), dist.group.WORLD, balance=balance, narrow=narrow, local_opts=Opts(2, 4, 4) if narrow else None)
     cnt, out = sj.join(shard(Rg), n_per_rank, shard(Sg), n_per_rank)
+    if narrow and n_per_rank >= 4_000:
+        assert sj.stats["format"] == "narrow12", sj.stats
+        assert sj.stats["exchange_bytes_sent"] == 12 * (2 * n_per_rank - sj.stats["kept_local"]), sj.stats
+    if not narrow:
+        assert sj.stats["format"] == "tuple16"
     pairs = out.numpy()[:cnt].view(np.uint64)
     # every pair this rank produced belongs to its owner class
     assert np.all(sj.owner_of(Rg["payload"][pairs[:, 0].astype(np.int64)]) == rank)
@@ -148,10 +196,10 @@ def run_world(world, *args):
     return stats
 
 
-@pytest.mark.parametrize("world,n_per_rank,dup,staged", [(2, 20_000, 1, True), (2, 5_000, 4, False), (4, 6_000, 2, True),
-                                                         (2, 1_000, 1, True), (3, 4_000, 1, True)])
-def test_sharded_join_equals_global_join(world, n_per_rank, dup, staged):
-    run_world(world, n_per_rank, dup, staged)
+@pytest.mark.parametrize("world,n_per_rank,dup,narrow", [(2, 20_000, 1, True), (2, 5_000, 4, False), (4, 6_000, 2, True),
+                                                         (2, 1_000, 1, True), (3, 4_000, 1, True), (3, 4_000, 3, False)])
+def test_sharded_join_equals_global_join(world, n_per_rank, dup, narrow):
+    run_world(world, n_per_rank, dup, narrow)
 
 
 def test_skewed_join_values_are_balanced_over_ranks():

@@ -414,7 +414,7 @@ def main():
             line["sharded"] = {"wire_format": sj.stats["format"], "exchange_bytes_per_rank": sj.stats["exchange_bytes_sent"],
                                "bytes_per_tuple_sent": {"narrow12": 12, "tuple16": 16}[sj.stats["format"]],
                                "recv_tuples_rank0": [sj.stats["recv_R"], sj.stats["recv_S"]],
-                               "local_plan": sj.stats.get("plan"), "backend": dist.get_backend(),
+                               "local_plan": sj.stats.get("plan"), "rowid_mode": sj.stats.get("rowid_mode"), "backend": dist.get_backend(),
                                "kernel_ms_per_step_rank0": {k: v[0] / args.steps for k, v in kt.items()},
                                "kernel_ms_note": "device time of rank 0's kernels, from extra steps outside the timed region"}
         if auto is not None:

@@ -167,16 +167,27 @@ int rhj_bucket_join(rhj_ctx *ctx, const rhj_tuple *d_Rp, const uint64_t *d_start
  *   4. all-to-all of the payload array and of the rowID array (same element counts; destination d gets classes
  *      [cut[d], cut[d+1]))
  *   5. rhj_shard_partition per relation              the local fused two-pass radix partition of what arrived (one histogram
- *      read of the payloads, two narrow scatter passes).  The receive buffer is nseg sender segments: pass-1 units are cut
- *      at the segment boundaries, and pass 2 stamps every tuple with its sender (low 4 payload bits, dead by then)
- *   6. rhj_shard_join                                bucket join of the two partitioned sides (Result.cpp:43-76 per bucket);
- *      a pair reports row0[sender] + local rowID for both sides: global rowIDs, as if one GPU had joined everything.
+ *      read of the payloads, two scatter passes).  The receive buffer is nseg sender segments; pass-1 units are cut at the
+ *      segment boundaries, so that pass 2 knows the sender of every tuple it moves and can restore GLOBAL rowIDs
+ *      (row0[sender] + local rowID), in the way `mode` names:
+ *        RHJ_SHARD_PLAIN     every rowID of both relations is < 2^32 and every rank split with key_base 0: nothing to restore,
+ *                            narrow partitions, the kernels of a single-GPU join
+ *        RHJ_SHARD_TAGGED    narrow partitions, the sender number in the low 4 payload bits (dead by then), resolved by the
+ *                            one-table bucket join (partitions that fit one LDS table)
+ *        RHJ_SHARD_GLOBAL16  pass 2 writes 16-byte tuples with global rowIDs (larger partitions: the compact-table kernel has
+ *                            no register left to carry tags in)
+ *   6. rhj_shard_join                                bucket join of the two partitioned sides (Result.cpp:43-76 per bucket):
+ *      global rowIDs, as if one GPU had joined everything.
  * Results stay sharded (every rank holds the pairs of the join values it owns).
- * rhj_shard_plan says whether sizes / plan fit this path (1) or the host must fall back to exchanging 16-byte tuples (0):
- * rhj_partition_at + all-to-all + rhj_join_dev. */
+ * rhj_shard_plan returns RHJ_SHARD_TAGGED or RHJ_SHARD_GLOBAL16 for sizes / plans that fit this path (the host may use
+ * RHJ_SHARD_PLAIN instead when the gathered rowID ranges allow it), or 0: fall back to exchanging 16-byte tuples
+ * (rhj_partition_at + all-to-all + rhj_join_dev). */
+#define RHJ_SHARD_TAGGED 1
+#define RHJ_SHARD_GLOBAL16 2
+#define RHJ_SHARD_PLAIN 3
 uint64_t rhj_narrow_key_offset(uint64_t n);               /* byte offset of the rowID array inside a narrow buffer of n tuples */
 uint64_t rhj_narrow_bytes(uint64_t n);                    /* bytes of a narrow buffer of n tuples (<= 16 n for n >= 1024) */
-int rhj_shard_plan(uint64_t nR, uint64_t nS, const rhj_opts *in, rhj_opts *resolved);   /* 1 / 0 / negative rhj_status */
+int rhj_shard_plan(uint64_t nR, uint64_t nS, const rhj_opts *in, rhj_opts *resolved);   /* mode / 0 / negative rhj_status */
 /* hist: HOST array of 2^bits counts; key_min / key_max: HOST words (may be NULL).  Synchronises.  side: 0 or 1 -- two sets of
  * unit tables, so that R and S can both be between their rhj_shard_stats and their rhj_shard_split. */
 int rhj_shard_stats(rhj_ctx *ctx, int side, const rhj_tuple *d_rel, uint64_t n, int shift, int bits, uint64_t *hist,
@@ -186,13 +197,12 @@ int rhj_shard_stats(rhj_ctx *ctx, int side, const rhj_tuple *d_rel, uint64_t n, 
 int rhj_shard_split(rhj_ctx *ctx, int side, const rhj_tuple *d_rel, uint64_t n, int shift, int bits, uint64_t key_base,
                     void *d_narrow_out, uint64_t *d_class_start);
 /* asynchronous; seg_off: HOST array of nseg + 1 offsets into the received arrays (seg_off[0] = 0, seg_off[nseg] = m),
- * segment s = what rank s sent; plan: a resolved two-pass plan for which rhj_shard_plan returned 1 (same on both sides) */
+ * segment s = what rank s sent; row0: HOST array of nseg rowID bases (the key_base each rank split this relation with);
+ * plan: the resolved two-pass plan rhj_shard_plan returned a mode for; plan and mode the same on both sides */
 int rhj_shard_partition(rhj_ctx *ctx, int side, const uint64_t *d_payloads, const uint32_t *d_rowids, uint64_t m, int nseg,
-                        const uint64_t *seg_off, const rhj_opts *plan);
-/* row0_R / row0_S: HOST arrays of nseg rowID bases (the key_base each rank split its shard with).  Count / overflow
- * behaviour of rhj_join_dev. */
-int rhj_shard_join(rhj_ctx *ctx, int nseg, const uint64_t *row0_R, const uint64_t *row0_S, rhj_pair *d_out, uint64_t out_capacity,
-                   uint64_t *out_count);
+                        const uint64_t *seg_off, const uint64_t *row0, const rhj_opts *plan, int mode);
+/* count / overflow behaviour of rhj_join_dev */
+int rhj_shard_join(rhj_ctx *ctx, rhj_pair *d_out, uint64_t out_capacity, uint64_t *out_count);
 
 /* ---- utilities -------------------------------------------------------------------------- */
 /* order-insensitive checksum of SURVEY.md App. A over a device pair array:

@@ -76,8 +76,8 @@ SYMBOLS = {
     "rhj_shard_plan": (C.c_int, [_u64, _u64, _P(Opts), _P(Opts)]),
     "rhj_shard_stats": (C.c_int, [_vp, C.c_int, _vp, _u64, C.c_int, C.c_int, _vp, _P(_u64), _P(_u64)]),
     "rhj_shard_split": (C.c_int, [_vp, C.c_int, _vp, _u64, C.c_int, C.c_int, _u64, _vp, _vp]),
-    "rhj_shard_partition": (C.c_int, [_vp, C.c_int, _vp, _vp, _u64, C.c_int, _vp, _P(Opts)]),
-    "rhj_shard_join": (C.c_int, [_vp, C.c_int, _vp, _vp, _vp, _u64, _P(_u64)]),
+    "rhj_shard_partition": (C.c_int, [_vp, C.c_int, _vp, _vp, _u64, C.c_int, _vp, _vp, _P(Opts), C.c_int]),
+    "rhj_shard_join": (C.c_int, [_vp, _vp, _u64, _P(_u64)]),
     "rhj_pairs_checksum_dev": (C.c_int, [_vp, _vp, _u64, _P(_u64)]),
     "rhj_generate_dev": (C.c_int, [_vp, C.c_int, _vp, _u64, _u64, _u64, _u64, C.c_int]),
     "rhj_expected_pkfk_dev": (C.c_int, [_vp, _vp, _u64, _P(_u64), _P(_u64)]),
@@ -131,14 +131,18 @@ def narrow_bytes(n):
     return load_library().rhj_narrow_bytes(n)
 
 
+SHARD_TAGGED, SHARD_GLOBAL16, SHARD_PLAIN = 1, 2, 3      # include/rhj.h: how the receiver restores global rowIDs
+
+
 def shard_plan(nR, nS, opts=None):
-    """(ok, plan): ok = the narrow sharded path (rhj_shard_*) serves a local join of these sizes under `plan`"""
+    """(mode, plan): mode = SHARD_TAGGED / SHARD_GLOBAL16 when the narrow sharded path (rhj_shard_*) serves a local join of
+    these sizes under `plan`, 0 when it does not (exchange 16-byte tuples instead)"""
     lib = load_library()
     out = Opts()
     rc = lib.rhj_shard_plan(nR, nS, C.byref(opts) if opts is not None else None, C.byref(out))
     if rc < 0:
         raise RhjError(rc, "bad options")
-    return rc == 1, out
+    return rc, out
 
 
 def _addr(x):
@@ -339,17 +343,16 @@ class Engine:
         self._chk(self.lib.rhj_shard_split(self.ctx, side, _addr(d_rel), n, shift, bits, key_base, _addr(d_narrow_out),
                                            _addr(d_class_start)))
 
-    def shard_partition(self, side, d_payloads, d_rowids, m, seg_off, plan):
+    def shard_partition(self, side, d_payloads, d_rowids, m, seg_off, row0, plan, mode):
+        assert len(row0) == len(seg_off) - 1
         seg = (C.c_uint64 * len(seg_off))(*[int(x) for x in seg_off])
-        self._chk(self.lib.rhj_shard_partition(self.ctx, side, _addr(d_payloads), _addr(d_rowids), m, len(seg_off) - 1, seg,
-                                               C.byref(plan)))
+        base = (C.c_uint64 * len(row0))(*[int(x) for x in row0])
+        self._chk(self.lib.rhj_shard_partition(self.ctx, side, _addr(d_payloads), _addr(d_rowids), m, len(seg_off) - 1, seg, base,
+                                               C.byref(plan), mode))
 
-    def shard_join(self, row0_R, row0_S, d_out=None, capacity=0, allow_overflow=False):
-        assert len(row0_R) == len(row0_S)
-        a = (C.c_uint64 * len(row0_R))(*[int(x) for x in row0_R])
-        b = (C.c_uint64 * len(row0_S))(*[int(x) for x in row0_S])
+    def shard_join(self, d_out=None, capacity=0, allow_overflow=False):
         n = _u64()
-        rc = self.lib.rhj_shard_join(self.ctx, len(row0_R), a, b, _addr(d_out), capacity, C.byref(n))
+        rc = self.lib.rhj_shard_join(self.ctx, _addr(d_out), capacity, C.byref(n))
         self._chk(rc, allow=(RHJ_E_OVERFLOW,) if allow_overflow else ())
         return n.value
 

@@ -78,7 +78,7 @@ struct rhj_ctx {
     u32 narrow_fail_streak = 0, narrow_skip = 0;
     bool narrow_off_once = false;      // the repeat of a join that fell back
     // multi-GPU receiver (rhj_shard_partition / rhj_shard_join): the partitions carry sender tags
-    int shard_nseg = 0;
+    int shard_nseg = 0, shard_mode[2] = {0, 0};
     bool shard_side_done[2] = {false, false};
     u64 shard_n[2] = {0, 0}, shard_kmin[2] = {0, 0}, shard_kmax[2] = {0, 0};
     rhj_opts shard_plan{};
@@ -396,6 +396,10 @@ struct FusedIn {
     const u32 *K = nullptr;
     int nseg = 0;
     const u64 *seg_off = nullptr;      // host, nseg + 1
+    // what pass 2 writes (segmented input): 0 narrow, rowIDs as they came; 1 narrow, sender tag in the low payload bits;
+    // 2 16-byte tuples with global rowIDs key_bases[sender] + rowID32 (key_bases: device, 16 u64)
+    int final_form = 0;
+    const u64 *key_bases = nullptr;
 };
 
 int partition_relation_fused(rhj_ctx *ctx, const FusedIn &in, u64 n, int b1, int b2, void *d_out, u64 *d_ps, int narrow = 0)
@@ -408,7 +412,8 @@ int partition_relation_fused(rhj_ctx *ctx, const FusedIn &in, u64 n, int b1, int
     u32 units1, per, ngroups, groups_per_seg = 0;
     u64 segL[16] = {0};
     if (segs) {
-        if (in.nseg < 1 || in.nseg > seg_max() || narrow != 2 || b1 < tag_bits())
+        if (in.nseg < 1 || in.nseg > seg_max() || narrow != 2 || b1 < tag_bits() || in.final_form < 0 || in.final_form > 2 ||
+            (in.final_form == 2 && !in.key_bases))
             return fail(ctx, RHJ_E_INVALID, "segmented input: 1..16 segments, narrow format, pass 1 of at least 4 bits");
         groups_per_seg = want_groups / (u32)in.nseg ? want_groups / (u32)in.nseg : 1u;
         ngroups = groups_per_seg * (u32)in.nseg;
@@ -486,10 +491,13 @@ int partition_relation_fused(rhj_ctx *ctx, const FusedIn &in, u64 n, int b1, int
     }
     {
         Span s(ctx, RHJ_K_SCATTER);
-        if (narrow)
+        if (segs && in.final_form == 2)
+            launch_scatter_ranges_n2a(ctx->stream, ctx->part_tmp.p, d_out, n, units2, b1, b2, (const u64 *)ctx->unit_base.p,
+                                      (const u64 *)ctx->grp_rng.p, in.key_bases, ngroups, groups_per_seg, wide);
+        else if (narrow)
             launch_scatter_ranges_narrow(ctx->stream, ctx->part_tmp.p, narrow == 2, d_out, n, units2, b1, b2,
                                          (const u64 *)ctx->unit_base.p, (const u64 *)ctx->grp_rng.p, wide,
-                                         segs ? ngroups : 0u, segs ? groups_per_seg : 0u);
+                                         segs && in.final_form == 1 ? ngroups : 0u, segs && in.final_form == 1 ? groups_per_seg : 0u);
         else
             launch_scatter_ranges(ctx->stream, ctx->part_tmp.p, d_out, units2, b1, b2, (const u64 *)ctx->unit_base.p,
                                   (const u64 *)ctx->grp_rng.p);
@@ -1241,7 +1249,9 @@ int rhj_shard_plan(uint64_t nR, uint64_t nS, const rhj_opts *in, rhj_opts *resol
     rhj_ctx probe;                                      // default options: which kernel would join partitions of this size
     const int tb = o.bits1 + o.bits2;
     const int kind = choose_join_kind(&probe, nR, nS, (u64)1 << tb, tb);
-    return (kind == JK_CT || kind == JK_CT_HALF || kind == JK_BKT) ? 1 : 0;
+    if (kind == JK_BKT) return RHJ_SHARD_TAGGED;
+    if (kind == JK_CT || kind == JK_CT_HALF) return RHJ_SHARD_GLOBAL16;
+    return 0;
 }
 
 int rhj_shard_stats(rhj_ctx *ctx, int side, const rhj_tuple *d_rel, uint64_t n, int shift, int bits, uint64_t *hist,
@@ -1323,12 +1333,16 @@ int rhj_shard_split(rhj_ctx *ctx, int side, const rhj_tuple *d_rel, uint64_t n, 
 }
 
 int rhj_shard_partition(rhj_ctx *ctx, int side, const uint64_t *d_payloads, const uint32_t *d_rowids, uint64_t m, int nseg,
-                        const uint64_t *seg_off, const rhj_opts *plan)
+                        const uint64_t *seg_off, const uint64_t *row0, const rhj_opts *plan, int mode)
 {
     RHJCHK(use_device(ctx));
-    if ((side != 0 && side != 1) || !plan || plan->passes != 2 || !seg_off || nseg < 1 || nseg > seg_max() || seg_off[0] != 0 ||
-        seg_off[nseg] != m || (m && (!d_payloads || !d_rowids)))
+    if ((side != 0 && side != 1) || !plan || plan->passes != 2 || !seg_off || !row0 || nseg < 1 || nseg > seg_max() ||
+        seg_off[0] != 0 || seg_off[nseg] != m || (m && (!d_payloads || !d_rowids)) ||
+        (mode != RHJ_SHARD_TAGGED && mode != RHJ_SHARD_GLOBAL16 && mode != RHJ_SHARD_PLAIN))
         return fail(ctx, RHJ_E_INVALID, "bad rhj_shard_partition argument");
+    if (mode == RHJ_SHARD_PLAIN)
+        for (int i = 0; i < nseg; i++)
+            if (row0[i] != 0) return fail(ctx, RHJ_E_INVALID, "RHJ_SHARD_PLAIN: every rank must have split with key_base 0");
     if (!fused_two_pass_ok(plan->bits1, plan->bits2) || !narrow_pass_ok(plan->bits1) || !narrow_pass_ok(plan->bits2) ||
         plan->bits1 < tag_bits() || m >= ((u64)1 << 32))
         return fail(ctx, RHJ_E_INVALID, "rhj_shard_partition: not a plan of the narrow format (see rhj_shard_plan)");
@@ -1347,6 +1361,11 @@ int rhj_shard_partition(rhj_ctx *ctx, int side, const uint64_t *d_payloads, cons
         HIPCHK(ctx, hipMemsetAsync(ctx->narrow_flag.p, 0, 64, ctx->stream));
     }
     ctx->counters_clean = false;
+    u64 bases[16] = {0};
+    for (int i = 0; i < nseg; i++) bases[i] = row0[i];
+    RHJCHK(ensure(ctx, ctx->tag_base, 2 * sizeof(bases)));
+    u64 *d_bases = (u64 *)ctx->tag_base.p + 16 * side;
+    HIPCHK(ctx, hipMemcpyAsync(d_bases, bases, sizeof(bases), hipMemcpyHostToDevice, ctx->stream));   // (pageable source: staged before the call returns)
     if (m == 0) {                                       // nothing arrived: all boundaries 0
         HIPCHK(ctx, hipMemsetAsync(ps.p, 0, (np + 1) * 8, ctx->stream));
     } else {
@@ -1355,39 +1374,40 @@ int rhj_shard_partition(rhj_ctx *ctx, int side, const uint64_t *d_payloads, cons
         in.K = (const u32 *)d_rowids;
         in.nseg = nseg;
         in.seg_off = (const u64 *)seg_off;
+        in.final_form = mode == RHJ_SHARD_TAGGED ? 1 : mode == RHJ_SHARD_GLOBAL16 ? 2 : 0;
+        in.key_bases = d_bases;
         RHJCHK(partition_relation_fused(ctx, in, m, plan->bits1, plan->bits2, part.p, (u64 *)ps.p, 2));
     }
     ctx->shard_side_done[side] = true;
     ctx->shard_n[side] = m;
     ctx->shard_nseg = nseg;
+    ctx->shard_mode[side] = mode;
     ctx->shard_plan = *plan;
     return RHJ_OK;
 }
 
-int rhj_shard_join(rhj_ctx *ctx, int nseg, const uint64_t *row0_R, const uint64_t *row0_S, rhj_pair *d_out, uint64_t out_capacity,
-                   uint64_t *out_count)
+int rhj_shard_join(rhj_ctx *ctx, rhj_pair *d_out, uint64_t out_capacity, uint64_t *out_count)
 {
     RHJCHK(use_device(ctx));
-    if (!out_count || !row0_R || !row0_S || nseg < 1 || nseg > seg_max())
-        return fail(ctx, RHJ_E_INVALID, "bad rhj_shard_join argument");
-    if (!ctx->shard_side_done[0] || !ctx->shard_side_done[1] || ctx->shard_nseg != nseg)
-        return fail(ctx, RHJ_E_INVALID, "rhj_shard_join: rhj_shard_partition both sides (0 and 1) with the same segment count first");
+    if (!out_count) return fail(ctx, RHJ_E_INVALID, "bad rhj_shard_join argument");
+    if (!ctx->shard_side_done[0] || !ctx->shard_side_done[1] || ctx->shard_mode[0] != ctx->shard_mode[1])
+        return fail(ctx, RHJ_E_INVALID, "rhj_shard_join: rhj_shard_partition both sides (0 and 1) in the same mode first");
     *out_count = 0;
     prof_reset(ctx);
     const u64 mR = ctx->shard_n[0], mS = ctx->shard_n[1];
     if (mR == 0 || mS == 0) return RHJ_OK;
-    u64 bases[32] = {0};
-    for (int i = 0; i < nseg; i++) { bases[i] = row0_R[i]; bases[16 + i] = row0_S[i]; }
-    RHJCHK(ensure(ctx, ctx->tag_base, sizeof(bases)));
-    HIPCHK(ctx, hipMemcpyAsync(ctx->tag_base.p, bases, sizeof(bases), hipMemcpyHostToDevice, ctx->stream));   // (pageable source: staged before the call returns)
+    const int mode = ctx->shard_mode[0];
     const int tb = ctx->shard_plan.bits1 + ctx->shard_plan.bits2;
-    ctx->cur_narrow = 2;
+    const bool narrow = mode != RHJ_SHARD_GLOBAL16;
+    if (mode == RHJ_SHARD_TAGGED && choose_join_kind(ctx, mR, mS, (u64)1 << tb, tb) != JK_BKT)
+        return fail(ctx, RHJ_E_INVALID, "rhj_shard_join: partitions this large need RHJ_SHARD_GLOBAL16 (see rhj_shard_plan)");
+    ctx->cur_narrow = narrow ? 2 : 0;
     ctx->last.passes = 2;
     ctx->last.bits1 = ctx->shard_plan.bits1;
     ctx->last.bits2 = ctx->shard_plan.bits2;
     int rc = join_phase_on(ctx, ctx->part_R.p, (const u64 *)ctx->ps_R.p, mR, ctx->part_S.p, (const u64 *)ctx->ps_S.p, mS,
-                           (u64)1 << tb, tb, (u32)ctx->shard_plan.probe_split, d_out, d_out ? out_capacity : 0, (u64 *)out_count, true,
-                           (const u64 *)ctx->tag_base.p, false);
+                           (u64)1 << tb, tb, (u32)ctx->shard_plan.probe_split, d_out, d_out ? out_capacity : 0, (u64 *)out_count, narrow,
+                           mode == RHJ_SHARD_TAGGED ? (const u64 *)ctx->tag_base.p : nullptr, false);
     if (rc == RHJ_RETRY_WIDE) return fail(ctx, RHJ_E_HIP, "rhj_shard_join: unexpected wide-rowID flag");
     RHJCHK(rc);
     if (d_out && *out_count > out_capacity) return fail(ctx, RHJ_E_OVERFLOW, "result buffer too small");

@@ -125,5 +125,8 @@ void launch_scatter_ranges_narrow(hipStream_t st, const void *d_in, bool in_narr
                                   int bits, const u64 *d_unit_base, const u64 *d_rng, u32 *d_overflow, u32 tag_groups = 0,
                                   u32 tag_div = 0, const u32 *d_inK = nullptr);   // d_inK: narrow input whose rowID array is not at narrow_k_offset(n)
 const char *launch_attr_error();                       // text of the first refused hipFuncSetAttribute, or null
+void launch_scatter_ranges_n2a(hipStream_t st, const void *d_in, void *d_out, u64 n, u32 nunits, int shift, int bits,
+                               const u64 *d_unit_base, const u64 *d_rng, const u64 *d_key_bases, u32 tag_groups, u32 tag_div,
+                               const u32 *d_skip);
 size_t scan_tmp_bytes(int bits);
 size_t part_lds_bytes(int bits);

@@ -682,15 +682,22 @@ k_scatter_units_pipe(const Tup *__restrict__ in, Tup *__restrict__ out, const u6
 // One workgroup of 1024 threads per CU (tile 64 KiB + carry lines nbins*128 B), next tile's 16 B/lane
 // loads prefetched into a second register set, 4 workgroup barriers per tile.
 // ------------------------------------------------------------------------------------------------
+// (multi-GPU receiver) pass-2 unit u holds tuples of sender (u % ngroups) / div; see k_scatter_wcn
+struct WnTag { u32 ngroups, div, bits; };   // bits == 0: no tagging
+constexpr u32 TAG_BITS = 4, TAG_MAX = 1u << TAG_BITS;   // sender tags in the low payload bits: <= 16 ranks (== SEG_MAX)
 constexpr int WC_THREADS = 1024, WC_TPT = 4;                                // geometry for 9-bit passes (tile = THREADS * WC_TPT)
 constexpr int WC_THREADS_SMALL = 512;                                       // <= 8 bits: two workgroups per CU
 constexpr int WC_MAX_BITS = 9;
 
-template <int THREADS>
+// IN_NARROW (multi-GPU receiver, last pass in front of the compact-table join): the input is a narrow relation whose rowIDs are
+// local to the sender's shard; unit u holds tuples of ONE sender (see WnTag) and the 16-byte tuples written carry the GLOBAL
+// rowID key_add + rowID32 -- the compact-table kernels then run unchanged on what one GPU would have partitioned itself.
+template <int THREADS, bool IN_NARROW = false>
 __device__ __forceinline__ void
 dev_scatter_wc(const Tup *__restrict__ in, Tup *__restrict__ out, const u64 *__restrict__ seg_start,
                const u32 *__restrict__ unit_start, u32 nseg, u64 L, int shift, int bits,
-               const u64 *__restrict__ unit_base, const u64 *__restrict__ unit_rng, u32 n_rng_units, const u32 u)
+               const u64 *__restrict__ unit_base, const u64 *__restrict__ unit_rng, u32 n_rng_units, const u32 u,
+               const u64 *__restrict__ inP = nullptr, const u32 *__restrict__ inK = nullptr, u64 key_add = 0)
 {
     constexpr int TILE = THREADS * WC_TPT;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -738,7 +745,8 @@ dev_scatter_wc(const Tup *__restrict__ in, Tup *__restrict__ out, const u64 *__r
 #pragma unroll
         for (int k = 0; k < WC_TPT; k++) {
             const u32 i = k * THREADS + tid;
-            t[k] = tp[i < last ? i : last];
+            if constexpr (IN_NARROW) { const u64 j = tb + (i < last ? i : last); t[k].payload = inP[j]; t[k].key = key_add + inK[j]; }
+            else t[k] = tp[i < last ? i : last];
         }
     };
     // FULL: the tile has TILE tuples (every tile of a unit but its last): no per-tuple range checks
@@ -861,6 +869,19 @@ k_scatter_wc(const Tup *__restrict__ in, Tup *__restrict__ out, const u64 *__res
     dev_scatter_wc<THREADS>(in, out, seg_start, unit_start, nseg, L, shift, bits, unit_base, unit_rng, n_rng_units, blockIdx.x);
 }
 
+// narrow in (explicit unit ranges, one sender per unit), 16-byte tuples with global rowIDs out
+template <int THREADS>
+__global__ void __launch_bounds__(THREADS)
+k_scatter_wc_n(const u64 *__restrict__ inP, const u32 *__restrict__ inK, Tup *__restrict__ out, int shift, int bits,
+               const u64 *__restrict__ unit_base, const u64 *__restrict__ unit_rng, u32 n_rng_units,
+               const u64 *__restrict__ key_bases, WnTag tag, const u32 *__restrict__ skip)
+{
+    if (skip != nullptr && *skip != 0) return;
+    const u64 add = key_bases[(blockIdx.x % tag.ngroups) / tag.div];
+    dev_scatter_wc<THREADS, true>(nullptr, out, nullptr, nullptr, 0u, 0, shift, bits, unit_base, unit_rng, n_rng_units, blockIdx.x,
+                                  inP, inK, add);
+}
+
 template <int THREADS>
 __global__ void __launch_bounds__(THREADS) k_scatter_wc2(PassPair a, int shift, int bits)
 {
@@ -891,8 +912,6 @@ constexpr int WN_THREADS = 1024, WN_TPT = 4, WN_GR = 32, WN_MAX_BITS = 8;
 //   sender segments of the receive buffer, so group g = u % tag.ngroups of pass-1 units belongs to sender g / tag.div); the
 //   low tag.bits bits of a payload -- constant inside the partition from here on, hence dead -- are replaced by that
 //   sender number, which the join kernels turn back into a global rowID (row0[sender] + local rowID).
-struct WnTag { u32 ngroups, div, bits; };   // bits == 0: no tagging
-constexpr u32 TAG_BITS = 4, TAG_MAX = 1u << TAG_BITS;   // sender tags in the low payload bits: <= 16 ranks (== SEG_MAX)
 
 template <bool IN_NARROW>
 __global__ void __launch_bounds__(WN_THREADS)
@@ -1292,11 +1311,16 @@ template <> struct RelView<true> {
     __device__ __forceinline__ u64 payload(u32 i) const { return p[i]; }
     __device__ __forceinline__ Rid rowid(u32 i) const { return k[i]; }
     __device__ __forceinline__ Both both(u32 i) const { return Both{k[i], p[i]}; }
-    __device__ __forceinline__ unsigned char tag(u32 i) const { return reinterpret_cast<const unsigned char *>(p)[(size_t)i * 8]; }   // low payload byte
 };
 
-// TAGGED / tag_base / skip: as in k_join_ct (multi-GPU receiver: sender number in the low TAG_BITS payload bits, rowIDs
-// local to the sender's shard).  Payloads are compared with the tag bits forced to 1 on both sides.
+// TAGGED (multi-GPU receiver, NARROW only): the low TAG_BITS bits of every payload hold the number of the rank the tuple
+// came from (written by the last partition pass, k_scatter_wcn's WnTag) and its rowID is local to that rank's shard: the
+// rowID a pair reports is tag_base[side][tag] + rowID32 (tag_base: 2 x 16 u64, R's bases then S's).  Payloads are compared
+// with the tag bits forced to 1 on both sides.  The payload stays in registers in this kernel, so the tags cost nothing;
+// the compact-table kernel has no register to carry them in (three more VGPRs through its probe phase spill 44; fetching
+// them again costs a second pass over the build payloads: measured 20 against 10 ms at 10^9 tuples): partitions for that
+// kernel get their global rowIDs from the last partition pass instead (k_scatter_wc<.., IN_NARROW>, 16-byte tuples out).
+// skip (optional): a device word that is non-zero when this join is going to be repeated in another format.
 template <int THREADS, int CHUNK, int BBITS, int EPT, bool DIRECT, bool NARROW = false, bool TAGGED = false>
 __global__ void __launch_bounds__(THREADS, 4)
 k_join_bkt(const RelView<NARROW> R, const RelView<NARROW> S, const JoinTask *__restrict__ tasks,
@@ -1578,19 +1602,14 @@ __device__ __forceinline__ u32 ct_bucket(u64 key)
 // boundaries into `stamps` (CT_NSTAMP words per workgroup); never set in production launches.
 constexpr int CT_NSTAMP = 16;
 
-// TAGGED (multi-GPU receiver, NARROW only): the low TAG_BITS bits of every payload hold the number of the rank the tuple
-// came from (written by the last partition pass, k_scatter_wcn's WnTag) and its rowID is local to that rank's shard: the
-// rowID a pair reports is tag_base[side][tag] + rowID32.  The tags ride through the kernel packed 4 bits per slot.
 // skip (optional): a device word that is non-zero when this join is going to be repeated in another format (a rowID did
 // not fit the narrow format): nothing to do then.
-template <int THREADS, int CHUNK, int BBITS, int EPT, bool STAMPS, bool NARROW, bool TAGGED = false>
+template <int THREADS, int CHUNK, int BBITS, int EPT, bool STAMPS, bool NARROW>
 __global__ void __launch_bounds__(THREADS, THREADS * (CHUNK <= 8960 ? 2 : 1) / 256)   // wavefronts per SIMD: 2 (256 registers per lane) or 4 (128)
 k_join_ct(const RelView<NARROW> R, const RelView<NARROW> S, const JoinTask *__restrict__ tasks,
           const u32 *__restrict__ ntasks, int radix_bits, Pair *__restrict__ out, u64 out_capacity,
-          u64 *__restrict__ out_count, u64 *__restrict__ stamps, u32 nstamp_wgs, const u64 *__restrict__ tag_base,
-          const u32 *__restrict__ skip)
+          u64 *__restrict__ out_count, u64 *__restrict__ stamps, u32 nstamp_wgs, const u32 *__restrict__ skip)
 {
-    static_assert(!TAGGED || NARROW, "sender tags exist in the narrow format only");
     if (skip != nullptr && *skip != 0) return;
     int stamp_i = 0;
     auto stamp = [&]() {
@@ -1617,14 +1636,11 @@ k_join_ct(const RelView<NARROW> R, const RelView<NARROW> S, const JoinTask *__re
     u64 *dummy = gres + 1;                                                   // target of the LDS writes of out-of-range slots:
     // range checks select an address instead of branching, so that the reads / atomics of a whole batch are in
     // flight together (a branch per slot costs one exposed LDS round trip each: measured 35 of them per build phase)
-    u64 *tbase = dummy + 1;                                                  // TAGGED: 2 x TAG_MAX rowID bases (R's, then S's)
 
     const u32 nt = *ntasks;
     if (blockIdx.x >= nt) return;
     const JoinTask task = tasks[blockIdx.x];
     const bool build_is_S = task.build_is_S != 0;
-    if (TAGGED && threadIdx.x < 2 * TAG_MAX) tbase[threadIdx.x] = tag_base[threadIdx.x];   // (visible after the first barrier)
-    const u32 btoff = build_is_S ? TAG_MAX : 0u, ptoff = build_is_S ? 0u : TAG_MAX;
     typedef typename RelView<NARROW>::Rid Rid;
     typedef typename RelView<NARROW>::Both Both;
     const RelView<NARROW> B = (build_is_S ? S : R).at(task.bbeg);
@@ -1702,9 +1718,6 @@ k_join_ct(const RelView<NARROW> R, const RelView<NARROW> S, const JoinTask *__re
                                                                              // (bit b: entry lo + b matches) << 16; 0 = none
         u32 deferred = 0;                                                    // wave-uniform: slots left to the generic loop
         u32 ctot = 0;                                                        // matches of this lane
-        // TAGGED: the sender tag of a probe slot rides in mi[k] between the position and a match mask of 12 instead of 16 bits
-        // (buckets average 1.9 entries; longer ones go through the generic loop): no register of its own
-        constexpr u32 MB = TAGGED ? CT_MASK_BITS - TAG_BITS : CT_MASK_BITS, MSH = 32 - MB;
         Both ring[DEPTH][PT];
         asm volatile("" : "+v"(tid), "+v"(nv));
 #pragma unroll
@@ -1723,8 +1736,7 @@ k_join_ct(const RelView<NARROW> R, const RelView<NARROW> S, const JoinTask *__re
                 const u32 h = ct_bucket<BBITS>(key);
                 khi[s] = (u32)(key >> 16); klo[s] = (u32)key << 16;
                 lo[s] = off16[h]; m[s] = 0;
-                if (TAGGED) lo[s] |= ((u32)ring[t % DEPTH][s].payload & (TAG_MAX - 1)) << 16;
-                len[s] = k < nv ? off16[h + 1] - (lo[s] & 0xFFFFu) : 0u;
+                len[s] = k < nv ? off16[h + 1] - lo[s] : 0u;
                 maxlen = len[s] > maxlen ? len[s] : maxlen;
             }
             if (t + DEPTH < NT) {                                            // the slot is free: next tile on its way
@@ -1732,14 +1744,14 @@ k_join_ct(const RelView<NARROW> R, const RelView<NARROW> S, const JoinTask *__re
                 for (int s = 0; s < PT; s++)
                     ring[t % DEPTH][s] = P.both((t + DEPTH) * PT + s < nv ? (u32)((t + DEPTH) * PT + s) * THREADS + tid : 0u);
             }
-            const bool longb = __ballot(maxlen > MB) != 0;                   // a long bucket somewhere: the generic loop
+            const bool longb = __ballot(maxlen > CT_MASK_BITS) != 0;         // a long bucket somewhere: the generic loop
             if (!longb) {
                 for (u32 j = 0; __ballot(j < maxlen) != 0; j++) {            // PT independent LDS reads per round
 #pragma unroll
                     for (int s = 0; s < PT; s++) {
-                        const u64 e = ent[(lo[s] & 0xFFFFu) + j];            // (past the bucket's end: some other entry, ignored)
+                        const u64 e = ent[lo[s] + j];                        // (past the bucket's end: some other entry, ignored)
                         const u32 xl = (u32)e ^ klo[s], xh = (u32)(e >> 32) ^ khi[s];
-                        if (j < len[s] && xh == 0 && xl < 0x10000u) m[s] |= (1u << MSH) << j;
+                        if (j < len[s] && xh == 0 && xl < 0x10000u) m[s] |= 0x10000u << j;
                     }
                 }
             }
@@ -1747,7 +1759,7 @@ k_join_ct(const RelView<NARROW> R, const RelView<NARROW> S, const JoinTask *__re
             for (int s = 0; s < PT; s++) {
                 const int k = t * PT + s;
                 if (longb) { deferred |= 1u << k; m[s] = 0; }
-                ctot += (u32)__popc(m[s] >> MSH);
+                ctot += (u32)__popc(m[s] >> 16);
                 mi[k] = m[s] ? (m[s] | lo[s]) : 0u;
             }
         }
@@ -1763,11 +1775,6 @@ k_join_ct(const RelView<NARROW> R, const RelView<NARROW> S, const JoinTask *__re
             deferred &= deferred - 1;
             const Both pt = P.both(k < nv ? (u32)k * THREADS + tid : 0u);
             const u64 key = pt.payload >> rb;
-            const u64 ptkey = TAGGED ? (u64)pt.key + tbase[ptoff + ((u32)pt.payload & (TAG_MAX - 1))] : (u64)pt.key;
-            // build rowID of arrival index i (TAGGED: + the base of the rank named in the low bits of its payload)
-            auto build_rowid = [&](u32 i) -> u64 {
-                return TAGGED ? (u64)B.rowid(i) + tbase[btoff + ((u32)B.payload(i) & (TAG_MAX - 1))] : (u64)B.rowid(i);
-            };
             u32 lo = 0, hi = 0;
             if (k < nv) { const u32 h = ct_bucket<BBITS>(key); lo = off16[h]; hi = off16[h + 1]; }
             unsigned long long heavy = __ballot(hi - lo > BJ_HEAVY);
@@ -1803,9 +1810,9 @@ k_join_ct(const RelView<NARROW> R, const RelView<NARROW> S, const JoinTask *__re
                     const u64 e = ent[j];
                     if ((e >> 16) == key) {
                         if (o < out_capacity) {
-                            const u64 br = build_rowid(cb + ((u32)e & 0xFFFFu));
+                            const u64 br = B.rowid(cb + ((u32)e & 0xFFFFu));
                             Pair pr;
-                            if (build_is_S) { pr.r = ptkey; pr.s = br; } else { pr.r = br; pr.s = ptkey; }
+                            if (build_is_S) { pr.r = pt.key; pr.s = br; } else { pr.r = br; pr.s = pt.key; }
                             out[o] = pr;
                         }
                         o++;
@@ -1817,7 +1824,7 @@ k_join_ct(const RelView<NARROW> R, const RelView<NARROW> S, const JoinTask *__re
                 while (hv) {
                     const int leader = __ffsll((long long)hv) - 1;
                     hv &= hv - 1;
-                    const u64 lkey = bj_readlane64(key, leader), lprid = bj_readlane64(ptkey, leader);
+                    const u64 lkey = bj_readlane64(key, leader), lprid = bj_readlane64((u64)pt.key, leader);
                     u64 ob = bj_readlane64(o, leader);
                     const u32 l = __builtin_amdgcn_readlane(lo, leader), hh = __builtin_amdgcn_readlane(hi, leader);
                     for (u32 j = l; j < hh; j += 64) {
@@ -1827,7 +1834,7 @@ k_join_ct(const RelView<NARROW> R, const RelView<NARROW> S, const JoinTask *__re
                         const unsigned long long bal = __ballot(mt);
                         const u64 dst = ob + (u64)__popcll(bal & lt);
                         if (mt && dst < out_capacity) {
-                            const u64 br = build_rowid(cb + ((u32)e & 0xFFFFu));
+                            const u64 br = B.rowid(cb + ((u32)e & 0xFFFFu));
                             Pair pr;
                             if (build_is_S) { pr.r = lprid; pr.s = br; } else { pr.r = br; pr.s = lprid; }
                             out[dst] = pr;
@@ -1844,18 +1851,13 @@ k_join_ct(const RelView<NARROW> R, const RelView<NARROW> S, const JoinTask *__re
         // take 70 more VGPRs through the probe phase (tried: the allocator spills them at their definition and the
         // build loads serialise behind the scratch stores); they are fetched again here instead, 8 of every 16 bytes of
         // a partition this CU streamed a few microseconds ago, while the barrier and the reservation go on.
-        // TAGGED: the sender tags of the build tuples (low byte of their payloads) are fetched again too, once the rowIDs
-        // are in LDS (three more registers held through the probe phase cost 44 spilled VGPRs, eighteen more here 34).
         Rid brid[BPT];
         {
             int tq = tid0;
             asm volatile("" : "+v"(tq));
             const int nvq = nc > (u32)tq ? (int)((nc - (u32)tq + THREADS - 1) / THREADS) : 0;
 #pragma unroll
-            for (int k = 0; k < BPT; k++) {
-                const u32 i = cb + (k < nvq ? (u32)k * THREADS + tq : 0u);
-                brid[k] = B.rowid(i);
-            }
+            for (int k = 0; k < BPT; k++) brid[k] = B.rowid(cb + (k < nvq ? (u32)k * THREADS + tq : 0u));
         }
         stamp();                                                             // 5: rowID loads issued
         if (lane == 0) wtot[w] = wave_total;
@@ -1866,17 +1868,8 @@ k_join_ct(const RelView<NARROW> R, const RelView<NARROW> S, const JoinTask *__re
             asm volatile("" : "+v"(td));
             const int nvd = nc > (u32)td ? (int)((nc - (u32)td + THREADS - 1) / THREADS) : 0;
 #pragma unroll
-            for (int k = 0; k < BPT; k++) {
-                *(k < nvd ? &rid[(k & 1) ? (ppos[k >> 1] >> 16) : (ppos[k >> 1] & 0xFFFFu)] : dummy) = (u64)brid[k];   // table order
-            }
-        }
-        unsigned char btg[TAGGED ? BPT : 1];                                 // (the rowID registers are free again)
-        if constexpr (TAGGED) {
-            int tg = tid0;
-            asm volatile("" : "+v"(tg));
-            const int nvg = nc > (u32)tg ? (int)((nc - (u32)tg + THREADS - 1) / THREADS) : 0;
-#pragma unroll
-            for (int k = 0; k < BPT; k++) btg[k] = B.tag(cb + (k < nvg ? (u32)k * THREADS + tg : 0u));
+            for (int k = 0; k < BPT; k++)
+                *(k < nvd ? &rid[(k & 1) ? (ppos[k >> 1] >> 16) : (ppos[k >> 1] & 0xFFFFu)] : dummy) = brid[k];   // table order
         }
         stamp();                                                             // 7: rowIDs in LDS
         const u32 mine = lane < NW ? wtot[lane] : 0u;
@@ -1884,17 +1877,6 @@ k_join_ct(const RelView<NARROW> R, const RelView<NARROW> S, const JoinTask *__re
         const u32 chunk_total = __shfl(inc, NW - 1, 64);
         const u32 wbase = __shfl(inc - mine, w, 64);
         if (tid == 0 && chunk_total) *gres = atomicAdd(out_count, (u64)chunk_total);
-        if constexpr (TAGGED) {                                              // rid[pos] = {sender | local rowID}, resolved when a pair is stored
-            int th = tid0;
-            asm volatile("" : "+v"(th));
-            const int nvh = nc > (u32)th ? (int)((nc - (u32)th + THREADS - 1) / THREADS) : 0;
-            unsigned char *rb8 = reinterpret_cast<unsigned char *>(rid);
-#pragma unroll
-            for (int k = 0; k < BPT; k++) {
-                const u32 pos = (k & 1) ? (ppos[k >> 1] >> 16) : (ppos[k >> 1] & 0xFFFFu);
-                *(k < nvh ? &rb8[(size_t)pos * 8 + 4] : reinterpret_cast<unsigned char *>(dummy)) = btg[k] & (unsigned char)(TAG_MAX - 1);
-            }
-        }
         __syncthreads();
         stamp();                                                             // 8: output reserved
         if (out != nullptr && wave_total) {
@@ -1902,7 +1884,7 @@ k_join_ct(const RelView<NARROW> R, const RelView<NARROW> S, const JoinTask *__re
 #pragma unroll
             for (int k = 0; k < EPT; k++) {
                 const u32 lo = mi[k] & 0xFFFFu;
-                u32 mask = mi[k] >> MSH;
+                u32 mask = mi[k] >> 16;
                 // round r stores the (r+1)-th match of every lane that has one: ballot + mbcnt compaction, consecutive
                 // lanes -> consecutive pairs.  One round in the FK case; no cross-lane scan with duplicates either.
                 for (unsigned long long bal = __ballot(mask != 0); bal != 0; bal = __ballot(mask != 0)) {
@@ -1911,15 +1893,10 @@ k_join_ct(const RelView<NARROW> R, const RelView<NARROW> S, const JoinTask *__re
                         const u32 bpos = (u32)__ffs((int)mask) - 1;
                         mask &= mask - 1;
                         if (dst < out_capacity) {
-                            u64 br = rid[lo + bpos];
-                            u64 pk = prid[k];
-                            if (TAGGED) {
-                                br = (u64)(u32)br + tbase[btoff + (u32)(br >> 32)];
-                                pk += tbase[ptoff + ((mi[k] >> 16) & (TAG_MAX - 1))];
-                            }
+                            const u64 br = rid[lo + bpos];
                             Pair pr;
-                            if (build_is_S) { pr.r = pk; pr.s = br; }           // orderFlag, Result.cpp:64-68
-                            else            { pr.r = br; pr.s = pk; }
+                            if (build_is_S) { pr.r = prid[k]; pr.s = br; }      // orderFlag, Result.cpp:64-68
+                            else            { pr.r = br; pr.s = prid[k]; }
                             typedef u64 u64x2 __attribute__((ext_vector_type(2)));
                             __builtin_nontemporal_store(u64x2{pr.r, pr.s}, reinterpret_cast<u64x2 *>(out + dst));
                         }
@@ -2059,7 +2036,7 @@ static int current_device_slot()
 
 static size_t ct_lds_bytes(int threads = CT_THREADS, int chunk = CT_CHUNK, int bbits = CT_BUCKET_BITS)
 {
-    return (size_t)chunk * 8 + ((size_t)(1 << bbits) / 2 + 2 + 2 * (threads / 64)) * 4 + 24 + 2 * TAG_MAX * 8;
+    return (size_t)chunk * 8 + ((size_t)(1 << bbits) / 2 + 2 + 2 * (threads / 64)) * 4 + 24;
 }
 
 // hipFuncSetAttribute results are kept: a refused LDS size would otherwise surface later as an anonymous launch failure.
@@ -2103,8 +2080,8 @@ static void allow_big_lds()
     SET_LDS((k_join_ct<CT_THREADS, CT_CHUNK, CT_BUCKET_BITS, CT_EPT, false, true>), ct_lds_bytes());
     SET_LDS((k_join_ct<CTH_THREADS, CTH_CHUNK, CTH_BUCKET_BITS, CT_EPT, false, true>), ct_lds_bytes(CTH_THREADS, CTH_CHUNK, CTH_BUCKET_BITS));
     SET_LDS((k_join_bkt<BJ_THREADS, BJ_CHUNK, BJ_BUCKET_BITS, BJ_EPT, false, true, true>), bj_lds_bytes(BJ_THREADS, BJ_CHUNK, BJ_BUCKET_BITS));
-    SET_LDS((k_join_ct<CT_THREADS, CT_CHUNK, CT_BUCKET_BITS, CT_EPT, false, true, true>), ct_lds_bytes());
-    SET_LDS((k_join_ct<CTH_THREADS, CTH_CHUNK, CTH_BUCKET_BITS, CT_EPT, false, true, true>), ct_lds_bytes(CTH_THREADS, CTH_CHUNK, CTH_BUCKET_BITS));
+    SET_LDS(k_scatter_wc_n<WC_THREADS>, wc_lds_bytes(WC_MAX_BITS, WC_THREADS));
+    SET_LDS(k_scatter_wc_n<WC_THREADS_SMALL>, wc_lds_bytes(WC_MAX_BITS, WC_THREADS_SMALL));
     SET_LDS(k_scatter_wcn<false>, wn_lds_bytes(WN_MAX_BITS));
     SET_LDS(k_scatter_wcn<true>, wn_lds_bytes(WN_MAX_BITS));
     });
@@ -2263,6 +2240,25 @@ void launch_scatter_ranges(hipStream_t st, const void *d_in, void *d_out, u32 nu
                            d_unit_base, d_rng, nunits);
 }
 
+// last pass of the multi-GPU receiver in front of the compact-table join: narrow in (rowIDs at narrow_k_offset(n)), 16-byte
+// tuples with global rowIDs out; d_key_bases: 16 u64 on the device, one per sender
+void launch_scatter_ranges_n2a(hipStream_t st, const void *d_in, void *d_out, u64 n, u32 nunits, int shift, int bits,
+                               const u64 *d_unit_base, const u64 *d_rng, const u64 *d_key_bases, u32 tag_groups, u32 tag_div,
+                               const u32 *d_skip)
+{
+    if (nunits == 0) return;
+    allow_big_lds();
+    const u64 *iP = (const u64 *)d_in;
+    const u32 *iK = (const u32 *)((const unsigned char *)d_in + narrow_k_offset(n));
+    const WnTag tag{tag_groups, tag_div, 0u};
+    if (wc_threads_for(bits) == WC_THREADS_SMALL)
+        hipLaunchKernelGGL(k_scatter_wc_n<WC_THREADS_SMALL>, dim3(nunits), dim3(WC_THREADS_SMALL), wc_lds_bytes(bits, WC_THREADS_SMALL),
+                           st, iP, iK, (Tup *)d_out, shift, bits, d_unit_base, d_rng, nunits, d_key_bases, tag, d_skip);
+    else
+        hipLaunchKernelGGL(k_scatter_wc_n<WC_THREADS>, dim3(nunits), dim3(WC_THREADS), wc_lds_bytes(bits, WC_THREADS), st, iP, iK,
+                           (Tup *)d_out, shift, bits, d_unit_base, d_rng, nunits, d_key_bases, tag, d_skip);
+}
+
 // Narrow-format scatters (k_scatter_wcn).  A narrow relation of n tuples lives in one buffer of >= 16 n bytes: payloads
 // (u64) at offset 0, rowIDs (u32) at narrow_k_offset(n).
 bool narrow_pass_ok(int bits) { return bits >= 1 && bits <= WN_MAX_BITS; }
@@ -2348,16 +2344,12 @@ void launch_join(hipStream_t st, const void *d_R, const u64 *d_startR, const voi
 #define LAUNCH_BKT_N(TG) hipLaunchKernelGGL((k_join_bkt<BJ_THREADS, BJ_CHUNK, BJ_BUCKET_BITS, BJ_EPT, false, true, TG>), dim3(grid), \
             dim3(BJ_THREADS), bj_lds_bytes(BJ_THREADS, BJ_CHUNK, BJ_BUCKET_BITS), st, nR, nS, d_tasks, d_ntasks, radix_bits, o,       \
             out_capacity, d_out_count, DirectJoin{}, d_tag_base, d_skip)
-#define LAUNCH_CT_N(T, C, B, TG) hipLaunchKernelGGL((k_join_ct<T, C, B, CT_EPT, false, true, TG>), dim3(grid), dim3(T),              \
-            ct_lds_bytes(T, C, B), st, nR, nS, d_tasks, d_ntasks, radix_bits, o, out_capacity, d_out_count, (u64 *)nullptr, 0u,      \
-            d_tag_base, d_skip)
-        const bool tg = d_tag_base != nullptr;
+#define LAUNCH_CT_N(T, C, B) hipLaunchKernelGGL((k_join_ct<T, C, B, CT_EPT, false, true>), dim3(grid), dim3(T),                      \
+            ct_lds_bytes(T, C, B), st, nR, nS, d_tasks, d_ntasks, radix_bits, o, out_capacity, d_out_count, (u64 *)nullptr, 0u, d_skip)
+        const bool tg = d_tag_base != nullptr;                              // sender tags: the one-table kernel only (the host sees to it)
         if (kind == JK_BKT) { if (tg) LAUNCH_BKT_N(true); else LAUNCH_BKT_N(false); }
-        else if (kind == JK_CT_HALF) {
-            if (tg) LAUNCH_CT_N(CTH_THREADS, CTH_CHUNK, CTH_BUCKET_BITS, true); else LAUNCH_CT_N(CTH_THREADS, CTH_CHUNK, CTH_BUCKET_BITS, false);
-        } else {                                                             // JK_CT (the host never asks for another kind here)
-            if (tg) LAUNCH_CT_N(CT_THREADS, CT_CHUNK, CT_BUCKET_BITS, true); else LAUNCH_CT_N(CT_THREADS, CT_CHUNK, CT_BUCKET_BITS, false);
-        }
+        else if (kind == JK_CT_HALF) LAUNCH_CT_N(CTH_THREADS, CTH_CHUNK, CTH_BUCKET_BITS);
+        else LAUNCH_CT_N(CT_THREADS, CT_CHUNK, CT_BUCKET_BITS);             // JK_CT (the host never asks for another kind here)
 #undef LAUNCH_BKT_N
 #undef LAUNCH_CT_N
         return;
@@ -2377,8 +2369,7 @@ void launch_join(hipStream_t st, const void *d_R, const u64 *d_startR, const voi
     if (kind == JK_CT_HALF) {
         hipLaunchKernelGGL((k_join_ct<CTH_THREADS, CTH_CHUNK, CTH_BUCKET_BITS, CT_EPT, false, false>), dim3(grid), dim3(CTH_THREADS),
                            ct_lds_bytes(CTH_THREADS, CTH_CHUNK, CTH_BUCKET_BITS), st, vR, vS, d_tasks,
-                           d_ntasks, radix_bits, (Pair *)d_out, out_capacity, d_out_count, (u64 *)nullptr, 0u,
-                           (const u64 *)nullptr, (const u32 *)nullptr);
+                           d_ntasks, radix_bits, (Pair *)d_out, out_capacity, d_out_count, (u64 *)nullptr, 0u, (const u32 *)nullptr);
         return;
     }
     static const bool want_stamps = getenv("RHJ_CT_STAMPS") != nullptr;
@@ -2389,7 +2380,7 @@ void launch_join(hipStream_t st, const void *d_R, const u64 *d_startR, const voi
         (void)hipMemsetAsync(d_st, 0, (size_t)nw * CT_NSTAMP * 8, st);
         hipLaunchKernelGGL((k_join_ct<CT_THREADS, CT_CHUNK, CT_BUCKET_BITS, CT_EPT, true, false>), dim3(grid), dim3(CT_THREADS),
                            ct_lds_bytes(), st, vR, vS, d_tasks, d_ntasks, radix_bits,
-                           (Pair *)d_out, out_capacity, d_out_count, d_st, nw, (const u64 *)nullptr, (const u32 *)nullptr);
+                           (Pair *)d_out, out_capacity, d_out_count, d_st, nw, (const u32 *)nullptr);
         std::vector<u64> h((size_t)nw * CT_NSTAMP);
         (void)hipMemcpyAsync(h.data(), d_st, h.size() * 8, hipMemcpyDeviceToHost, st);
         (void)hipStreamSynchronize(st);
@@ -2414,7 +2405,7 @@ void launch_join(hipStream_t st, const void *d_R, const u64 *d_startR, const voi
     }
     hipLaunchKernelGGL((k_join_ct<CT_THREADS, CT_CHUNK, CT_BUCKET_BITS, CT_EPT, false, false>), dim3(grid), dim3(CT_THREADS),
                        ct_lds_bytes(), st, vR, vS, d_tasks, d_ntasks, radix_bits,
-                       (Pair *)d_out, out_capacity, d_out_count, (u64 *)nullptr, 0u, (const u64 *)nullptr, (const u32 *)nullptr);
+                       (Pair *)d_out, out_capacity, d_out_count, (u64 *)nullptr, 0u, (const u32 *)nullptr);
 }
 
 // Unpartitioned join of two small relations in ONE launch: build side = S when nR >= nS (JobScheduler.cpp:187).

@@ -20,9 +20,11 @@ Schedule of the narrow path (include/rhj.h "multi-GPU stage entry points"; all c
   4. all_to_all_single of the payload array and of the rowID array per relation (RCCL: world-1 direct peer sends
      over xGMI, all links busy at once, no multi-hop); R is on the wire while S is being split;
   5. rhj_shard_partition: the local fused two-pass partition of what arrived (one 8 B/tuple histogram read, two
-     12 B + 12 B scatter passes); pass-1 units are cut at the sender segments of the receive buffer and pass 2 stamps
-     every tuple with its sender; the partitioning of R overlaps the transfer of S;
-  6. rhj_shard_join: the bucket join resolves sender + local rowID into the global rowID.
+     scatter passes); pass-1 units are cut at the sender segments of the receive buffer, so pass 2 knows every tuple's
+     sender and restores global rowIDs (rowIDs all below 2^32: nothing to restore; else a sender tag in dead payload
+     bits for the one-table join, or 16-byte tuples with global rowIDs for the compact-table join: include/rhj.h);
+     the partitioning of R overlaps the transfer of S;
+  6. rhj_shard_join: the bucket join.
 Why the class split is NOT pass 1 of the local plan: two 8-bit passes separate 16 bits in all, and the
 ownership of a tuple uses up log2(world) of them -- 8 x 10^9 tuples need 19 bits, three passes, wherever the exchange sits.
 
@@ -128,19 +130,26 @@ class ShardedJoin:
         mR, mS = sum(outR), sum(outS)
         self.stats = {"recv_R": mR, "recv_S": mS, "cuts": list(self.cuts), "format": "tuple16"}
         # one decision for all ranks, from gathered numbers only
-        spanok = all(_u64(meta["head"][r][3]) - _u64(meta["head"][r][2]) < (1 << 32) and
-                     _u64(meta["head"][r][5]) - _u64(meta["head"][r][4]) < (1 << 32) for r in range(self.world))
-        narrow = all(meta["head"][r][6] for r in range(self.world)) and spanok
-        plan = None
+        head = meta["head"]
+        spanok = all(_u64(head[r][3]) - _u64(head[r][2]) < (1 << 32) and _u64(head[r][5]) - _u64(head[r][4]) < (1 << 32)
+                     for r in range(self.world))
+        narrow = all(head[r][6] for r in range(self.world)) and spanok
+        plan, mode = None, 0
         if narrow:
-            from .binding import shard_plan
-            ok, plan = shard_plan(max(meta["recvR"]), max(meta["recvS"]), self.local_opts)
-            narrow = ok and min(meta["recvR"]) >= 0
-        if not narrow:
+            from .binding import SHARD_PLAIN, shard_plan
+            mode, plan = shard_plan(max(meta["recvR"]), max(meta["recvS"]), self.local_opts)
+            # rowIDs that are all below 2^32 travel as they are (key_base 0 on every rank): the receiver has nothing to restore
+            if mode and all(_u64(head[r][3]) < (1 << 32) and _u64(head[r][5]) < (1 << 32) for r in range(self.world)):
+                mode = SHARD_PLAIN
+        if not mode:
             return self._join_tuple16(R, nR, S, nS, inR, outR, inS, outS, out)
 
         from .binding import narrow_bytes, narrow_key_offset
+        plain = mode == SHARD_PLAIN
+        row0R = [0 if plain else _u64(head[r][2]) for r in range(self.world)]
+        row0S = [0 if plain else _u64(head[r][4]) for r in range(self.world)]
         self.stats["format"] = "narrow12"
+        self.stats["rowid_mode"] = {1: "tagged", 2: "global16", 3: "plain"}[mode]
         self.stats["kept_local"] = inR[self.rank] + inS[self.rank]
         self.stats["exchange_bytes_sent"] = 12 * ((nR - inR[self.rank]) + (nS - inS[self.rank]))
         self.stats["plan"] = (plan.passes, plan.bits1, plan.bits2)
@@ -160,8 +169,8 @@ class ShardedJoin:
             w2 = self._a2a(rK[:m], K, out_splits, in_splits, async_op=True)
             return rP, rK, m, (w1, w2), buf          # buf must stay alive until the transfer has finished
 
-        hR = split_and_send(0, R, nR, _u64(meta["head"][self.rank][2]), inR, outR)      # R on the wire ...
-        hS = split_and_send(1, S, nS, _u64(meta["head"][self.rank][4]), inS, outS)      # ... while S is being split
+        hR = split_and_send(0, R, nR, row0R[self.rank], inR, outR)      # R on the wire ...
+        hS = split_and_send(1, S, nS, row0S[self.rank], inS, outS)      # ... while S is being split
 
         def seg_offsets(out_splits):
             off = [0]
@@ -173,23 +182,21 @@ class ShardedJoin:
             if w is not None:
                 w.wait()                               # (stream-level wait: the host runs on)
         self._fence_torch(dev)
-        eng.shard_partition(0, hR[0], hR[1], mR, seg_offsets(outR), plan)      # R's local passes overlap the S transfer
+        eng.shard_partition(0, hR[0], hR[1], mR, seg_offsets(outR), row0R, plan, mode)   # R's local passes overlap the S transfer
         self._collect()
         for w in hS[3]:
             if w is not None:
                 w.wait()
         self._fence_torch(dev)
-        eng.shard_partition(1, hS[0], hS[1], mS, seg_offsets(outS), plan)
+        eng.shard_partition(1, hS[0], hS[1], mS, seg_offsets(outS), row0S, plan, mode)
         self._collect()
-        row0R = [_u64(meta["head"][r][2]) for r in range(self.world)]
-        row0S = [_u64(meta["head"][r][4]) for r in range(self.world)]
         cap = out.shape[0] if out is not None else max(mR, mS) + 1024
         if out is None:
             out = torch.empty((cap, 2), dtype=torch.int64, device=dev)
-        cnt = eng.shard_join(row0R, row0S, out, cap, allow_overflow=True)
+        cnt = eng.shard_join(out, cap, allow_overflow=True)
         if cnt > cap:                                  # more pairs than guessed: the exact size is known now
             out = torch.empty((cnt, 2), dtype=torch.int64, device=dev)
-            cnt = eng.shard_join(row0R, row0S, out, cnt)
+            cnt = eng.shard_join(out, cnt)
         self._collect()
         return cnt, out
 

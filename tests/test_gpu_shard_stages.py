@@ -9,7 +9,7 @@ import pytest
 
 from oracle.pyoracle import TUPLE
 from radixhashjoin_amd import Engine, Opts
-from radixhashjoin_amd.binding import narrow_bytes, narrow_key_offset, shard_plan
+from radixhashjoin_amd.binding import SHARD_GLOBAL16, SHARD_PLAIN, SHARD_TAGGED, narrow_bytes, narrow_key_offset, shard_plan
 from radixhashjoin_amd.sharded import balanced_cuts
 
 pytestmark = pytest.mark.gpu
@@ -23,7 +23,7 @@ def few_partitions(values, nlow):
     return (values << np.uint64(16)) | lows[(values % np.uint64(nlow)).astype(np.int64)]
 
 
-def sharded_join(eng, shardsR, shardsS, plan):
+def sharded_join(eng, shardsR, shardsS, plan, mode):
     """the schedule of radixhashjoin_amd/sharded.py with the collectives replaced by host slicing; returns all pairs"""
     world = len(shardsR)
     C = 1 << BITS
@@ -38,6 +38,8 @@ def sharded_join(eng, shardsR, shardsS, plan):
             assert (kmin, kmax) == (int(t["key"].min()), int(t["key"].max()))
             buf = eng.alloc(max(narrow_bytes(n), 16))
             starts = eng.alloc(8 * (C + 1))
+            if mode == SHARD_PLAIN:
+                kmin = 0                                                     # rowIDs travel as they are
             eng.shard_split(side, d, n, SHIFT, BITS, kmin, buf, starts)
             raw = buf.to_numpy(np.uint8, narrow_bytes(n))
             P = raw[:8 * n].view(np.uint64).copy()
@@ -70,21 +72,19 @@ def sharded_join(eng, shardsR, shardsS, plan):
             m = off[-1]
             dP = eng.to_device(np.concatenate(Ps) if m else np.zeros(1, dtype=np.uint64))
             dK = eng.to_device(np.concatenate(Ks) if m else np.zeros(1, dtype=np.uint32))
-            eng.shard_partition(side, dP, dK, m, off, plan)
+            eng.shard_partition(side, dP, dK, m, off, [x[3] for x in sent[side]], plan, mode)
             eng.sync()
             dP.free(); dK.free()
-        row0R = [x[3] for x in sent[0]]
-        row0S = [x[3] for x in sent[1]]
-        cnt = eng.shard_join(row0R, row0S, None, 0)                         # count only
+        cnt = eng.shard_join(None, 0)                                       # count only
         out = eng.alloc(16 * max(cnt, 1))
-        assert eng.shard_join(row0R, row0S, out, cnt) == cnt
+        assert eng.shard_join(out, cnt) == cnt
         pairs.append(out.to_numpy(np.uint64, 2 * cnt).reshape(-1, 2))
         out.free()
     return np.concatenate(pairs)
 
 
-def global_relations(rng, world, n_per, nlow, dup):
-    """R, S as lists of shards; rowIDs global, shard r's in [r * 5 * 2^30, ...): beyond 2^32 from rank 1 on"""
+def global_relations(rng, world, n_per, nlow, dup, stride=5 << 30):
+    """R, S as lists of shards; rowIDs global, shard r's in [r * stride, ...): with the default beyond 2^32 from rank 1 on"""
     nglob = n_per * world
     vals = rng.permutation(1 << 24)[:max(nglob // dup, 1)].astype(np.uint64)
     rv = vals[rng.integers(0, len(vals), nglob)] if dup > 1 else vals[:nglob]
@@ -94,7 +94,7 @@ def global_relations(rng, world, n_per, nlow, dup):
         out = []
         for r in range(world):
             t = np.empty(n_per, dtype=TUPLE)
-            t["key"] = rng.permutation(n_per).astype(np.uint64) + np.uint64(r * 5 * (1 << 30) + 12345)
+            t["key"] = rng.permutation(n_per).astype(np.uint64) + np.uint64(r * stride + 12345)
             pv = v[r * n_per:(r + 1) * n_per]
             t["payload"] = few_partitions(pv, nlow) if nlow else pv * np.uint64(0x9E3779B97F4A7C15)
             out.append(t)
@@ -102,25 +102,28 @@ def global_relations(rng, world, n_per, nlow, dup):
     return shards(rv), shards(sv)
 
 
-@pytest.mark.parametrize("world,n_per,nlow,dup,plan,kernel", [
-    (3, 60_000, 0, 1, Opts(2, 4, 4), BKT),           # one-table kernel, tagged; 3 ranks
-    (2, 50_000, 0, 3, Opts(2, 5, 3), BKT),           # duplicates on both sides
-    (8, 20_000, 4, 1, Opts(2, 8, 8), CT),            # compact-table kernel, 8 ranks, 40 K-tuple partitions (chunks, split tasks)
-    (4, 30_000, 12, 2, Opts(2, 8, 8), CT),           # duplicates: the generic (wavefront, slot) loop with tags
-    (2, 40_000, 9, 1, Opts(2, 8, 8), CT_HALF),       # half-size compact table
-    (5, 9_000, 3, 1, Opts(2, 8, 8), CT),
+@pytest.mark.parametrize("world,n_per,nlow,dup,plan,kernel,mode", [
+    (3, 60_000, 0, 1, Opts(2, 4, 4), BKT, SHARD_TAGGED),           # one-table kernel resolving sender tags; 3 ranks
+    (2, 50_000, 0, 3, Opts(2, 5, 3), BKT, SHARD_TAGGED),           # duplicates on both sides
+    (8, 20_000, 4, 1, Opts(2, 8, 8), CT, SHARD_GLOBAL16),          # compact-table kernel, 8 ranks, 40 K-tuple partitions (chunks, split tasks)
+    (4, 30_000, 12, 2, Opts(2, 8, 8), CT, SHARD_GLOBAL16),         # duplicates: the generic (wavefront, slot) loop
+    (2, 40_000, 9, 1, Opts(2, 8, 8), CT_HALF, SHARD_GLOBAL16),     # half-size compact table
+    (5, 9_000, 3, 1, Opts(2, 8, 8), CT, SHARD_GLOBAL16),
+    (3, 40_000, 0, 2, Opts(2, 6, 6), BKT, SHARD_GLOBAL16),         # 16-byte final partitions into the one-table kernel works too
+    (4, 30_000, 5, 1, Opts(2, 8, 8), CT, SHARD_PLAIN),             # rowIDs below 2^32: narrow end to end, nothing to restore
+    (3, 50_000, 0, 2, Opts(2, 5, 5), BKT, SHARD_PLAIN),
 ])
-def test_shard_stage_calls_equal_global_join(oracle, world, n_per, nlow, dup, plan, kernel):
+def test_shard_stage_calls_equal_global_join(oracle, world, n_per, nlow, dup, plan, kernel, mode):
     rng = np.random.default_rng(world * 1000 + n_per)
-    Rs, Ss = global_relations(rng, world, n_per, nlow, dup)
-    ok, rplan = shard_plan(n_per, n_per, plan)
-    assert ok == 1 or ok is True
+    Rs, Ss = global_relations(rng, world, n_per, nlow, dup, stride=(1 << 30) if mode == SHARD_PLAIN else (5 << 30))
+    suggested, rplan = shard_plan(n_per, n_per, plan)
+    assert suggested == SHARD_TAGGED                # (sizes this small: one table per partition)
     eng = Engine(0)
     try:
         if kernel != BKT:
             eng.set_option("join.big_tables", 1)
             eng.set_option("join.big_kernel", kernel)
-        got = sharded_join(eng, Rs, Ss, rplan)
+        got = sharded_join(eng, Rs, Ss, rplan, mode)
         assert eng.info("last.join_kernel") == kernel
     finally:
         eng.close()
@@ -130,7 +133,7 @@ def test_shard_stage_calls_equal_global_join(oracle, world, n_per, nlow, dup, pl
     e = np.stack([exp["keyR"], exp["keyS"]], axis=1)
     e = e[np.lexsort((e[:, 1], e[:, 0]))]
     assert np.array_equal(a, e)
-    assert got[:, 0].max() >= (1 << 32)                                     # the tags really had to resolve wide rowIDs
+    assert (got[:, 0].max() >= (1 << 32)) == (mode != SHARD_PLAIN)          # (else) the receiver really had to restore wide rowIDs
 
 
 def test_shard_split_refuses_a_base_that_does_not_fit(engine):

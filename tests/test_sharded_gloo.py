@@ -79,17 +79,18 @@ class OracleEngine:
         koff = narrow_key_offset(n)
         buf[koff:koff + 4 * n] = local.astype(np.uint32).view(np.uint8)
 
-    def shard_partition(self, side, d_payloads, d_rowids, m, seg_off, plan):
-        assert plan.passes == 2 and seg_off[0] == 0 and seg_off[-1] == m
+    def shard_partition(self, side, d_payloads, d_rowids, m, seg_off, row0, plan, mode):
+        assert plan.passes == 2 and seg_off[0] == 0 and seg_off[-1] == m and mode in (1, 2, 3)
+        assert mode != 3 or not any(row0)
         sender = np.repeat(np.arange(len(seg_off) - 1), np.diff(np.asarray(seg_off, dtype=np.int64)))
         self._recv = getattr(self, "_recv", {})
-        self._recv[side] = (d_payloads.numpy()[:m].view(np.uint64).copy(), d_rowids.numpy()[:m].view(np.uint32).copy(), sender)
+        self._recv[side] = (d_payloads.numpy()[:m].view(np.uint64).copy(), d_rowids.numpy()[:m].view(np.uint32).copy(), sender, row0)
 
-    def shard_join(self, row0_R, row0_S, d_out=None, capacity=0, allow_overflow=False):
+    def shard_join(self, d_out=None, capacity=0, allow_overflow=False):
         from oracle.pyoracle import TUPLE
         rel = []
-        for side, row0 in ((0, row0_R), (1, row0_S)):
-            P, K, sender = self._recv[side]
+        for side in (0, 1):
+            P, K, sender, row0 = self._recv[side]
             t = np.empty(len(P), dtype=TUPLE)
             t["payload"] = P
             t["key"] = np.asarray(row0, dtype=np.uint64)[sender] + K.astype(np.uint64)       # global rowID = sender's base + local

@@ -7,6 +7,8 @@
 
 #include <atomic>
 #include <chrono>
+#include <condition_variable>
+#include <functional>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -35,6 +37,59 @@ struct Prof {
 
 }  // namespace
 
+// Host -> HBM copies of PAGEABLE caller memory (the reference allocates relations with new[]).  [measured, one MI355X host]
+// hipMemcpy from pageable memory 15-18 GB/s, from pinned memory 57.5 GB/s; hipHostRegister of the caller's array 60 ms per GiB
+// (more than the copy itself); memcpy pageable -> pinned 24-30 GB/s per thread.  So: STAGE_BUFS pinned 16 MiB buffers filled
+// by STAGE_WORKERS persistent threads (whole chunks each, > 100 GB/s together), DMA'd out in order by the calling thread on the
+// copy stream: the wire runs at the pinned rate.
+constexpr size_t STAGE_BYTES = (size_t)16 << 20;
+constexpr int STAGE_BUFS = 8, STAGE_WORKERS = 6;
+
+struct Stager {
+    void *buf[STAGE_BUFS] = {nullptr};
+    hipEvent_t ev[STAGE_BUFS] = {nullptr};
+    std::vector<std::thread> workers;
+    std::mutex mu;
+    std::condition_variable cv;
+    bool quit = false;
+    u64 job_id = 0;                        // bumped for every copy; workers pick the job up once
+    int device = 0;
+    // the current job
+    const char *src = nullptr;
+    size_t bytes = 0, nchunks = 0;
+    std::atomic<size_t> next{0}, issued{0}, chunk0{0};
+    std::atomic<int> active{0};
+    std::vector<std::atomic<unsigned char>> filled;
+    size_t total_chunks = 0;               // chunks DMA'd since the buffers were created (buffer = chunk number % STAGE_BUFS)
+
+    void work()
+    {
+        (void)hipSetDevice(device);
+        u64 seen = 0;
+        for (;;) {
+            {
+                std::unique_lock<std::mutex> lk(mu);
+                cv.wait(lk, [&] { return quit || job_id != seen; });
+                if (quit) return;
+                seen = job_id;
+            }
+            for (;;) {
+                const size_t c = next.fetch_add(1);
+                if (c >= nchunks) break;
+                const size_t g = chunk0.load() + c;                      // global chunk number: buffer g % STAGE_BUFS
+                if (g >= (size_t)STAGE_BUFS) {                            // the buffer's previous chunk must be on the device
+                    while (issued.load(std::memory_order_acquire) + STAGE_BUFS <= g) std::this_thread::yield();
+                    (void)hipEventSynchronize(ev[g % STAGE_BUFS]);
+                }
+                const size_t off = c * STAGE_BYTES, len = bytes - off < STAGE_BYTES ? bytes - off : STAGE_BYTES;
+                memcpy(buf[g % STAGE_BUFS], src + off, len);
+                filled[c].store(1, std::memory_order_release);
+            }
+            active.fetch_sub(1);
+        }
+    }
+};
+
 struct rhj_ctx {
     int device = 0;
     hipStream_t own_stream = nullptr;
@@ -60,9 +115,9 @@ struct rhj_ctx {
     std::vector<std::pair<void *, size_t>> free_blocks;
     size_t free_bytes = 0;
     // pinned staging for host -> HBM copies of pageable caller memory (rhj_join)
-    void *stage[2] = {nullptr, nullptr};
-    hipEvent_t stage_ev[2] = {nullptr, nullptr};
-    bool stage_busy[2] = {false, false};   // an async copy out of the buffer has been enqueued (wait on stage_ev before reuse)
+    Stager *stager = nullptr;
+    hipStream_t copy_stream = nullptr;     // uploads of rhj_join: S travels while R is being partitioned
+    hipEvent_t up_ev[2] = {nullptr, nullptr};
     // state of the last partition phase (consumed by join_phase)
     const void *cur_R = nullptr, *cur_S = nullptr;
     const u64 *cur_psR = nullptr, *cur_psS = nullptr;
@@ -137,39 +192,70 @@ void release(DevBuf &b)
     b.cap = 0;
 }
 
-// Host -> HBM copy of PAGEABLE caller memory (the reference allocates relations with new[]).  A plain
-// hipMemcpy from pageable memory reaches ~16 GB/s on an MI355X host; staging 16 MiB chunks through two pinned
-// buffers (two-way threaded memcpy, chunk k+1 copied while chunk k is on the wire) reaches the PCIe rate.
-constexpr size_t STAGE_BYTES = (size_t)16 << 20;
+void stager_destroy(rhj_ctx *ctx)
+{
+    Stager *st = ctx->stager;
+    if (!st) return;
+    {
+        std::lock_guard<std::mutex> lk(st->mu);
+        st->quit = true;
+    }
+    st->cv.notify_all();
+    for (std::thread &t : st->workers) t.join();
+    for (int i = 0; i < STAGE_BUFS; i++) {
+        if (st->buf[i]) (void)hipHostFree(st->buf[i]);
+        if (st->ev[i]) (void)hipEventDestroy(st->ev[i]);
+    }
+    delete st;
+    ctx->stager = nullptr;
+}
 
-int h2d_staged(rhj_ctx *ctx, void *d_dst, const void *src, size_t bytes)
+// asynchronous with respect to the device: returns when the last chunk's DMA has been ENQUEUED on `stream` (the source has
+// been read completely by then)
+int h2d_staged(rhj_ctx *ctx, void *d_dst, const void *src, size_t bytes, hipStream_t stream)
 {
     if (bytes < 4 * STAGE_BYTES) {
-        HIPCHK(ctx, hipMemcpyAsync(d_dst, src, bytes, hipMemcpyHostToDevice, ctx->stream));
+        HIPCHK(ctx, hipMemcpyAsync(d_dst, src, bytes, hipMemcpyHostToDevice, stream));
         return RHJ_OK;
     }
-    for (int i = 0; i < 2; i++) {
-        if (!ctx->stage[i]) {
-            HIPCHK(ctx, hipHostMalloc(&ctx->stage[i], STAGE_BYTES, hipHostMallocDefault));
-            HIPCHK(ctx, hipEventCreateWithFlags(&ctx->stage_ev[i], hipEventDisableTiming));
+    if (!ctx->stager) {
+        Stager *st = new Stager();
+        st->device = ctx->device;
+        ctx->stager = st;
+        for (int i = 0; i < STAGE_BUFS; i++) {
+            HIPCHK(ctx, hipHostMalloc(&st->buf[i], STAGE_BYTES, hipHostMallocDefault));
+            HIPCHK(ctx, hipEventCreateWithFlags(&st->ev[i], hipEventDisableTiming));
         }
+        for (int i = 0; i < STAGE_WORKERS; i++) st->workers.emplace_back([st] { st->work(); });
     }
-    size_t off = 0;
-    for (int k = 0; off < bytes; k ^= 1) {
-        const size_t len = bytes - off < STAGE_BYTES ? bytes - off : STAGE_BYTES;
-        if (ctx->stage_busy[k]) HIPCHK(ctx, hipEventSynchronize(ctx->stage_ev[k]));   // the DMA out of this buffer has finished
-        const char *from = (const char *)src + off;
-        char *to = (char *)ctx->stage[k];
-        const size_t half = (len / 2) & ~(size_t)63;
-        std::thread helper([=] { memcpy(to + half, from + half, len - half); });
-        memcpy(to, from, half);
-        helper.join();
-        HIPCHK(ctx, hipMemcpyAsync((char *)d_dst + off, to, len, hipMemcpyHostToDevice, ctx->stream));
-        HIPCHK(ctx, hipEventRecord(ctx->stage_ev[k], ctx->stream));
-        ctx->stage_busy[k] = true;
-        off += len;
+    Stager *st = ctx->stager;
+    const size_t nchunks = (bytes + STAGE_BYTES - 1) / STAGE_BYTES;
+    {
+        std::lock_guard<std::mutex> lk(st->mu);
+        st->src = (const char *)src;
+        st->bytes = bytes;
+        st->nchunks = nchunks;
+        st->filled = std::vector<std::atomic<unsigned char>>(nchunks);
+        for (auto &f : st->filled) f.store(0);
+        st->next.store(0);
+        st->chunk0.store(st->total_chunks);
+        st->issued.store(st->total_chunks);
+        st->active.store(STAGE_WORKERS);
+        st->job_id++;
     }
-    return RHJ_OK;
+    st->cv.notify_all();
+    int rc = RHJ_OK;
+    for (size_t c = 0; c < nchunks; c++) {
+        while (!st->filled[c].load(std::memory_order_acquire)) std::this_thread::yield();
+        const size_t g = st->total_chunks + c, off = c * STAGE_BYTES, len = bytes - off < STAGE_BYTES ? bytes - off : STAGE_BYTES;
+        hipError_t e = hipMemcpyAsync((char *)d_dst + off, st->buf[g % STAGE_BUFS], len, hipMemcpyHostToDevice, stream);
+        if (e == hipSuccess) e = hipEventRecord(st->ev[g % STAGE_BUFS], stream);
+        if (e != hipSuccess && rc == RHJ_OK) rc = fail(ctx, RHJ_E_HIP, std::string("staged upload: ") + hipGetErrorString(e));
+        st->issued.store(g + 1, std::memory_order_release);              // (on an error too: the workers must not wait for ever)
+    }
+    while (st->active.load() != 0) std::this_thread::yield();             // every worker has left the job
+    st->total_chunks += nchunks;
+    return rc;
 }
 
 int use_device(rhj_ctx *ctx)
@@ -574,8 +660,18 @@ bool is_direct(const rhj_ctx *ctx, u64 nparts, u64 nR, u64 nS)
 }
 
 // Partition phase of a join: leaves ctx->cur_* describing partitioned R and S.
-int partition_phase(rhj_ctx *ctx, const void *d_R, u64 nR, const void *d_S, u64 nS, const rhj_opts &plan)
+// before_S (optional, consumed by the first call that gets it): invoked once, after the kernels that partition R have been
+// enqueued and before anything reads S -- rhj_join uploads S there, so that S crosses PCIe while R is being partitioned
+// (plans that push both relations through the same launches call it first).
+int partition_phase(rhj_ctx *ctx, const void *d_R, u64 nR, const void *d_S, u64 nS, const rhj_opts &plan,
+                    std::function<int()> *before_S = nullptr)
 {
+    auto s_ready = [&]() -> int {
+        if (!before_S || !*before_S) return RHJ_OK;
+        std::function<int()> f;
+        f.swap(*before_S);
+        return f();
+    };
     ctx->cur_nR = nR;
     ctx->cur_nS = nS;
     ctx->cur_probe_split = (u32)plan.probe_split;
@@ -590,6 +686,7 @@ int partition_phase(rhj_ctx *ctx, const void *d_R, u64 nR, const void *d_S, u64 
         HIPCHK(ctx, hipMemsetAsync(ctx->narrow_flag.p, 0, 64, ctx->stream));
     }
     if (plan.passes == 0) {
+        RHJCHK(s_ready());
         RHJCHK(ensure(ctx, ctx->ps_R, 64));
         RHJCHK(ensure(ctx, ctx->ps_S, 64));
         if (!is_direct(ctx, 1, nR, nS)) {                               // boundaries {0, n} for the task list (the direct launch needs none)
@@ -610,12 +707,15 @@ int partition_phase(rhj_ctx *ctx, const void *d_R, u64 nR, const void *d_S, u64 
         RHJCHK(ensure(ctx, ctx->part_S, (size_t)(nS ? nS : 1) * 16));
         if (ctx->cur_narrow) {
             RHJCHK(partition_relation_fused(ctx, d_R, nR, plan.bits1, plan.bits2, ctx->part_R.p, (u64 *)ctx->ps_R.p, ctx->cur_narrow));
+            RHJCHK(s_ready());
             RHJCHK(partition_relation_fused(ctx, d_S, nS, plan.bits1, plan.bits2, ctx->part_S.p, (u64 *)ctx->ps_S.p, ctx->cur_narrow));
         } else if (plan.passes == 1 && plan.bits1 <= PASS_PAIR_MAX_BITS) {
+            RHJCHK(s_ready());
             RHJCHK(run_pass_pair(ctx, d_R, nR, ctx->part_R.p, (u64 *)ctx->ps_R.p, d_S, nS, ctx->part_S.p, (u64 *)ctx->ps_S.p,
                                  plan.bits1));
         } else {
             RHJCHK(partition_relation(ctx, d_R, nR, plan.passes, plan.bits1, plan.bits2, ctx->part_R.p, (u64 *)ctx->ps_R.p));
+            RHJCHK(s_ready());
             RHJCHK(partition_relation(ctx, d_S, nS, plan.passes, plan.bits1, plan.bits2, ctx->part_S.p, (u64 *)ctx->ps_S.p));
         }
         ctx->cur_R = ctx->part_R.p;
@@ -705,9 +805,9 @@ int join_phase(rhj_ctx *ctx, void *d_out, u64 cap, u64 *out_count)
 // partition + join.  A run in the narrow format whose histogram kernel met a rowID >= 2^32 costs two histogram launches
 // (every later kernel of the run returns at once) and is repeated in the 16-byte format; the fall-back is per join.
 int partition_and_join(rhj_ctx *ctx, const void *d_R, u64 nR, const void *d_S, u64 nS, const rhj_opts &plan, void *d_out,
-                       u64 cap, u64 *out_count)
+                       u64 cap, u64 *out_count, std::function<int()> *before_S = nullptr)
 {
-    int rc = partition_phase(ctx, d_R, nR, d_S, nS, plan);
+    int rc = partition_phase(ctx, d_R, nR, d_S, nS, plan, before_S);
     if (rc != RHJ_OK) { ctx->counters_clean = false; return rc; }
     const bool tried_narrow = ctx->cur_narrow != 0;
     if (!tried_narrow && ctx->narrow_skip > 0 && plan.passes == 2) ctx->narrow_skip--;
@@ -813,11 +913,7 @@ int rhj_release_workspace(rhj_ctx *ctx)
     ctx->free_blocks.clear();
     ctx->free_bytes = 0;
     if (ctx->h_land) { (void)hipHostFree(ctx->h_land); ctx->h_land = nullptr; }
-    for (int i = 0; i < 2; i++) {
-        if (ctx->stage[i]) { (void)hipHostFree(ctx->stage[i]); ctx->stage[i] = nullptr; }
-        if (ctx->stage_ev[i]) { (void)hipEventDestroy(ctx->stage_ev[i]); ctx->stage_ev[i] = nullptr; }
-        ctx->stage_busy[i] = false;
-    }
+    stager_destroy(ctx);
     return RHJ_OK;
 }
 
@@ -827,6 +923,8 @@ void rhj_destroy(rhj_ctx *ctx)
     (void)hipSetDevice(ctx->device);
     (void)rhj_release_workspace(ctx);
     for (hipEvent_t ev : ctx->prof.pool) (void)hipEventDestroy(ev);
+    for (int i = 0; i < 2; i++) if (ctx->up_ev[i]) (void)hipEventDestroy(ctx->up_ev[i]);
+    if (ctx->copy_stream) (void)hipStreamDestroy(ctx->copy_stream);
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
     delete ctx;
 }
@@ -1078,6 +1176,13 @@ int rhj_join(rhj_ctx *ctx, const rhj_tuple *R, uint64_t nR, const rhj_tuple *S, 
     // optimistic capacity: a foreign-key join yields about max(|R|,|S|) pairs; the count is exact
     // either way, and an overflow only repeats the join phase (partitions stay in the workspace)
     u64 cap = (nR > nS ? nR : nS) + 1024;
+    static const bool trace = getenv("RHJ_TRACE_JOIN") != nullptr;        // tuning aid: host-side timeline on stderr
+    auto now = [] { return std::chrono::steady_clock::now(); };
+    auto ms = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) {
+        return std::chrono::duration<double, std::milli>(b - a).count();
+    };
+    const auto t0 = now();
+    std::chrono::steady_clock::time_point tR = t0, tS = t0, tK = t0;
     PagePrefault pre;
     pre.start((size_t)cap);                           // host page being faulted in while the GPU side proceeds
     int rc = RHJ_OK;
@@ -1085,11 +1190,27 @@ int rhj_join(rhj_ctx *ctx, const rhj_tuple *R, uint64_t nR, const rhj_tuple *S, 
     auto body = [&]() -> int {
         RHJCHK(ensure(ctx, ctx->in_R, (size_t)nR * 16));
         RHJCHK(ensure(ctx, ctx->in_S, (size_t)nS * 16));
-        RHJCHK(h2d_staged(ctx, ctx->in_R.p, R, (size_t)nR * 16));
-        RHJCHK(h2d_staged(ctx, ctx->in_S.p, S, (size_t)nS * 16));
         RHJCHK(ensure(ctx, ctx->out_pairs, (size_t)cap * 16));
         u64 dcap = ctx->out_pairs.cap / 16;
-        RHJCHK(partition_and_join(ctx, ctx->in_R.p, nR, ctx->in_S.p, nS, plan, ctx->out_pairs.p, dcap, &count));
+        // uploads on their own stream: R first; S while the kernels that partition R run (the host is busy staging S by then)
+        if (!ctx->copy_stream) {
+            HIPCHK(ctx, hipStreamCreateWithFlags(&ctx->copy_stream, hipStreamNonBlocking));
+            for (int i = 0; i < 2; i++) HIPCHK(ctx, hipEventCreateWithFlags(&ctx->up_ev[i], hipEventDisableTiming));
+        }
+        HIPCHK(ctx, hipEventRecord(ctx->up_ev[0], ctx->stream));          // (earlier work of this context may still read in_R)
+        HIPCHK(ctx, hipStreamWaitEvent(ctx->copy_stream, ctx->up_ev[0], 0));
+        RHJCHK(h2d_staged(ctx, ctx->in_R.p, R, (size_t)nR * 16, ctx->copy_stream));
+        tR = now();
+        HIPCHK(ctx, hipEventRecord(ctx->up_ev[0], ctx->copy_stream));
+        HIPCHK(ctx, hipStreamWaitEvent(ctx->stream, ctx->up_ev[0], 0));
+        std::function<int()> upload_S = [&]() -> int {
+            RHJCHK(h2d_staged(ctx, ctx->in_S.p, S, (size_t)nS * 16, ctx->copy_stream));
+            HIPCHK(ctx, hipEventRecord(ctx->up_ev[1], ctx->copy_stream));
+            HIPCHK(ctx, hipStreamWaitEvent(ctx->stream, ctx->up_ev[1], 0));
+            tS = now();
+            return RHJ_OK;
+        };
+        RHJCHK(partition_and_join(ctx, ctx->in_R.p, nR, ctx->in_S.p, nS, plan, ctx->out_pairs.p, dcap, &count, &upload_S));
         if (count > dcap) {
             RHJCHK(ensure(ctx, ctx->out_pairs, (size_t)count * 16));
             dcap = ctx->out_pairs.cap / 16;
@@ -1100,6 +1221,7 @@ int rhj_join(rhj_ctx *ctx, const rhj_tuple *R, uint64_t nR, const rhj_tuple *S, 
         return RHJ_OK;
     };
     rc = body();
+    tK = now();
     if (rc != RHJ_OK || count == 0) {                 // count == 0: head stays nullptr (Result::isEmpty)
         pre.drop();
         return rc;
@@ -1123,6 +1245,10 @@ int rhj_join(rhj_ctx *ctx, const rhj_tuple *R, uint64_t nR, const rhj_tuple *S, 
     hipError_t e = hipMemcpyAsync(page + 8, ctx->out_pairs.p, (size_t)count * 16, hipMemcpyDeviceToHost, ctx->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
     if (e != hipSuccess) { free(page); return fail(ctx, RHJ_E_HIP, std::string("result copy: ") + hipGetErrorString(e)); }
+    if (trace)
+        fprintf(stderr, "[rhj_join %llu x %llu -> %llu] R staged %.1f  S staged %.1f  kernels + count %.1f  result copy %.1f  total %.1f ms\n",
+                (unsigned long long)nR, (unsigned long long)nS, (unsigned long long)count, ms(t0, tR), ms(tR, tS), ms(tS, tK),
+                ms(tK, now()), ms(t0, now()));
     *out_page = page;
     *out_count = count;
     return RHJ_OK;

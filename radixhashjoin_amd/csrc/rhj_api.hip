@@ -361,7 +361,10 @@ int resolve_plan(u64 nR, u64 nS, const rhj_opts *in, rhj_opts *out, bool device_
                 // 10^9 x 10^9, 8+8 bits 43 ms against 49 ms for 9+9.  Beyond 1.1 * 10^9 tuples per side a 16-bit partition
                 // no longer fits ONE compact table (chunks: probe payloads streamed again per chunk) and 9+9 bits (the
                 // widest line-aligned write-combining scatter) takes over: 2.2 * 10^9 x 2.2 * 10^9, 121.6 against 125.3 ms.
-                if (bits > 16) bits = nb <= (u64)65536 * 16800 ? 16 : 18;
+                // 17 bits (9+8) while the average partition stays inside one compact table (its probe side inside one task of 16 or
+                // 20 slots per thread), 18 (9+9) beyond; both run in the narrow format with 16-tuple carry lines in their 9-bit passes (k_scatter_wcn
+                // <GR = 16>) and a second, 8 B/tuple histogram read of the narrow intermediate.
+                if (bits > 16) bits = nb <= (u64)65536 * 16800 ? 16 : nb <= (u64)131072 * 16800 ? 17 : 18;
                 o.passes = 2; o.bits1 = (bits + 1) / 2; o.bits2 = bits / 2;
             }
         }
@@ -598,6 +601,54 @@ int partition_relation_fused(rhj_ctx *ctx, const void *d_in, u64 n, int b1, int 
     return partition_relation_fused(ctx, in, n, b1, b2, d_out, d_ps, narrow);
 }
 
+// Two narrow passes with SEPARATE histograms (plans of 17-18 bits: 2^(b1+b2) packed counters do not fit the LDS, so the
+// histogram of pass 2 is a second read -- of the narrow intermediate, 8 B/tuple): 16-byte tuples -> narrow part_tmp -> narrow
+// d_out.  A rowID >= 2^32 raises ctx->narrow_flag in pass 1 (every later kernel of the join returns at once).
+int partition_relation_narrow2(rhj_ctx *ctx, const void *d_in, u64 n, int b1, int b2, void *d_out, u64 *d_ps)
+{
+    RHJCHK(ensure(ctx, ctx->seg0, 64));
+    RHJCHK(ensure(ctx, ctx->part_tmp, (size_t)(n ? n : 1) * 16));
+    RHJCHK(ensure(ctx, ctx->ps_1, (((size_t)1 << b1) + 1) * 8));
+    u32 *wide = (u32 *)ctx->narrow_flag.p;
+    for (int pass = 0; pass < 2; pass++) {
+        const int bits = pass ? b2 : b1, shift = pass ? b1 : 0;
+        const u32 nseg = pass ? 1u << b1 : 1u;
+        const u64 *seg_start = pass ? (const u64 *)ctx->ps_1.p : (const u64 *)ctx->seg0.p;
+        u64 *part_start = pass ? d_ps : (u64 *)ctx->ps_1.p;
+        const PassGeom g = make_geom(n, nseg, shift, bits);
+        const size_t nbins = (size_t)1 << bits;
+        RHJCHK(ensure(ctx, ctx->unit_start, ((size_t)nseg + 1) * 4));
+        RHJCHK(ensure(ctx, ctx->unit_hist, (size_t)g.max_units * nbins * 4));
+        RHJCHK(ensure(ctx, ctx->unit_base, (size_t)g.max_units * nbins * 8));
+        RHJCHK(ensure(ctx, ctx->scan_tmp, scan_tmp_bytes(bits)));
+        u32 *unit_start = (u32 *)ctx->unit_start.p;
+        {
+            Span s(ctx, RHJ_K_AUX);
+            if (!pass) launch_init_single_segment(ctx->stream, n, g.L, (u64 *)ctx->seg0.p, unit_start);
+            else launch_make_units(ctx->stream, seg_start, nseg, g.L, unit_start);
+        }
+        {
+            Span s(ctx, RHJ_K_HIST);
+            if (!pass) launch_hist_units(ctx->stream, d_in, g, seg_start, unit_start, (u32 *)ctx->unit_hist.p);
+            else launch_hist_units_narrow(ctx->stream, ctx->part_tmp.p, g, seg_start, unit_start, (u32 *)ctx->unit_hist.p);
+        }
+        {
+            Span s(ctx, RHJ_K_SCAN);
+            launch_scan_units(ctx->stream, g, seg_start, unit_start, (const u32 *)ctx->unit_hist.p, (u64 *)ctx->unit_base.p,
+                              part_start, (u64 *)ctx->scan_tmp.p);
+        }
+        {
+            Span s(ctx, RHJ_K_SCATTER);
+            void *out = pass ? d_out : ctx->part_tmp.p;
+            launch_scatter_units_narrow_any(ctx->stream, pass ? ctx->part_tmp.p : d_in,
+                                            pass ? (const u32 *)((const unsigned char *)ctx->part_tmp.p + narrow_k_offset(n)) : nullptr,
+                                            out, (u32 *)((unsigned char *)out + narrow_k_offset(n)), g, seg_start, unit_start,
+                                            (const u64 *)ctx->unit_base.p, wide);
+        }
+    }
+    return check_launch(ctx, "two-pass narrow partition");
+}
+
 // Partition one relation with `passes` passes into d_out; boundaries into d_ps[2^(b1+b2) + 1].
 int partition_relation(rhj_ctx *ctx, const void *d_in, u64 n, int passes, int b1, int b2, void *d_out, u64 *d_ps)
 {
@@ -616,18 +667,30 @@ int partition_relation(rhj_ctx *ctx, const void *d_in, u64 n, int passes, int b1
 // Average build partition larger than one 4224-tuple table (an explicit plan with too few bits, or more than 2^30
 // tuples): the compact-table kernel when the plan removed enough payload bits for 48-bit keys, else 8448-tuple
 // chunks.  The compact-table kernel keeps a task's probe rowIDs in registers, so a task is at most that many tuples.
-int choose_join_kind(const rhj_ctx *ctx, u64 nR, u64 nS, u64 nparts, int radix_bits)
+int choose_join_kind(const rhj_ctx *ctx, u64 nR, u64 nS, u64 nparts, int radix_bits, bool narrow = false)
 {
     const u64 nbuild = nR < nS ? nR : nS;
     if (!(ctx->opt_big_tables == 1 || (ctx->opt_big_tables < 0 && nbuild / nparts > (u64)BJ_CHUNK))) return JK_BKT;
     if (radix_bits < join_ct_min_radix_bits() || ctx->opt_big_kernel == JK_BKT_BIG) return JK_BKT_BIG;
     if (ctx->opt_big_kernel == JK_CT || ctx->opt_big_kernel == JK_CT_HALF) return ctx->opt_big_kernel;
+    if (ctx->opt_big_kernel == JK_CT_WIDE) return narrow ? JK_CT_WIDE : JK_CT;
+    if (ctx->opt_big_kernel == JK_CT_HALF_WIDE) return narrow ? JK_CT_HALF_WIDE : JK_CT_HALF;
     // the compact-table kernel at half size (two workgroups per CU) while the average partition fits its table
     // AND its 8192-tuple probe tasks (a partition cut into two tasks builds its table twice)
-    const u64 nprobe = nR < nS ? nS : nR;
-    const bool half = nbuild / nparts <= (u64)join_table_tuples(JK_CT_HALF) * 15 / 16 &&
-                      nprobe / nparts <= (u64)join_probe_split(JK_CT_HALF) * 15 / 16;
-    return half ? JK_CT_HALF : JK_CT;
+    const u64 nprobe = nR < nS ? nS : nR, ab = nbuild / nparts, ap = nprobe / nparts;
+    auto fits = [&](int k) { return ab <= (u64)join_table_tuples(k) * 15 / 16 && ap <= (u64)join_probe_split(k) * 15 / 16; };
+    if (fits(JK_CT_HALF)) return JK_CT_HALF;
+    // 20 probe slots per thread (narrow partitions only) before a partition's probe side is cut into two tasks that build the
+    // table twice: [measured] 2.2 * 10^9 x 2.2 * 10^9, join kernel 32.5 ms with two 16-slot tasks per partition
+    if (narrow && fits(JK_CT_HALF_WIDE)) return JK_CT_HALF_WIDE;
+    if (fits(JK_CT)) return JK_CT;
+    if (narrow && fits(JK_CT_WIDE)) return JK_CT_WIDE;
+    return JK_CT;
+}
+
+bool narrow_fused_plan(const rhj_opts &plan)
+{
+    return fused_two_pass_ok(plan.bits1, plan.bits2) && narrow_pass_ok(plan.bits1) && narrow_pass_ok(plan.bits2);
 }
 
 // The narrow intermediate format applies to fused two-pass plans (both passes <= 8 bits) whose bucket join is the one-table
@@ -637,14 +700,16 @@ int narrow_level(const rhj_ctx *ctx, u64 nR, u64 nS, const rhj_opts &plan)
 {
     static const int env = (int)env_u64("RHJ_NARROW", 2, 0, 2);
     const int want = ctx->opt_narrow >= 0 ? ctx->opt_narrow : env;
-    if (want <= 0 || ctx->narrow_off_once || plan.passes != 2 || !fused_two_pass_ok(plan.bits1, plan.bits2)) return 0;
+    if (want <= 0 || ctx->narrow_off_once || plan.passes != 2) return 0;
     if (ctx->opt_narrow < 0 && ctx->narrow_skip > 0) return 0;              // backing off after repeated wide rowIDs (automatic mode only)
-    if (!narrow_pass_ok(plan.bits1) || !narrow_pass_ok(plan.bits2)) return 0;
+    const bool fused = narrow_fused_plan(plan);
+    // plans beyond 16 bits: two narrow passes with separate histograms (level 2 only), 9-bit passes in the 16-tuple-line geometry
+    if (!fused && !(want >= 2 && plan.bits1 + plan.bits2 > 16 && narrow_pass9_ok(plan.bits1) && narrow_pass9_ok(plan.bits2))) return 0;
     const u64 lo = nR < nS ? nR : nS, hi = nR < nS ? nS : nR;
     if (lo < NARROW_MIN_TUPLES || hi >= ((u64)1 << 32)) return 0;
     const int tb = plan.bits1 + plan.bits2;
-    const int kind = choose_join_kind(ctx, nR, nS, (u64)1 << tb, tb);
-    if (kind != JK_CT && kind != JK_CT_HALF && kind != JK_BKT) return 0;
+    const int kind = choose_join_kind(ctx, nR, nS, (u64)1 << tb, tb, true);
+    if (kind == JK_BKT_BIG) return 0;
     // the narrow scatter has one 1024-thread workgroup per CU and 32-tuple lines to start and finish per digit and unit:
     // below a few million tuples its fixed costs outweigh the bytes it saves (forced levels, used by the tests, skip this)
     static const u64 min_auto = env_u64("RHJ_NARROW_MIN", NARROW_AUTO_MIN_TUPLES, 0, ~0ull);
@@ -705,7 +770,11 @@ int partition_phase(rhj_ctx *ctx, const void *d_R, u64 nR, const void *d_S, u64 
         RHJCHK(ensure(ctx, ctx->ps_S, (np + 1) * 8));
         RHJCHK(ensure(ctx, ctx->part_R, (size_t)(nR ? nR : 1) * 16));
         RHJCHK(ensure(ctx, ctx->part_S, (size_t)(nS ? nS : 1) * 16));
-        if (ctx->cur_narrow) {
+        if (ctx->cur_narrow && !narrow_fused_plan(plan)) {
+            RHJCHK(partition_relation_narrow2(ctx, d_R, nR, plan.bits1, plan.bits2, ctx->part_R.p, (u64 *)ctx->ps_R.p));
+            RHJCHK(s_ready());
+            RHJCHK(partition_relation_narrow2(ctx, d_S, nS, plan.bits1, plan.bits2, ctx->part_S.p, (u64 *)ctx->ps_S.p));
+        } else if (ctx->cur_narrow) {
             RHJCHK(partition_relation_fused(ctx, d_R, nR, plan.bits1, plan.bits2, ctx->part_R.p, (u64 *)ctx->ps_R.p, ctx->cur_narrow));
             RHJCHK(s_ready());
             RHJCHK(partition_relation_fused(ctx, d_S, nS, plan.bits1, plan.bits2, ctx->part_S.p, (u64 *)ctx->ps_S.p, ctx->cur_narrow));
@@ -738,8 +807,8 @@ int join_phase_on(rhj_ctx *ctx, const void *d_Rp, const u64 *d_psR, u64 nR, cons
     if (probe_split == 0) probe_split = 32768;
     // a task addresses its build range with 32 bits; k_make_tasks reports any partition whose build side is larger
     // (counters[5], checked below) whatever the plan
-    const int kind = choose_join_kind(ctx, nR, nS, nparts, radix_bits);
-    if (narrow && kind != JK_CT && kind != JK_CT_HALF && kind != JK_BKT)
+    const int kind = choose_join_kind(ctx, nR, nS, nparts, radix_bits, narrow);
+    if (narrow && kind != JK_CT && kind != JK_CT_HALF && kind != JK_BKT && kind != JK_CT_WIDE && kind != JK_CT_HALF_WIDE)
         return fail(ctx, RHJ_E_INVALID, "no bucket-join kernel for narrow partitions under this plan");
     if (join_probe_split(kind) && probe_split > join_probe_split(kind)) probe_split = join_probe_split(kind);
     const u64 max_tasks64 = nparts + (nR + nS) / probe_split + 1;
@@ -942,7 +1011,7 @@ int rhj_set_option(rhj_ctx *ctx, const char *name, int64_t value)
     if (!ctx || !name) return fail(ctx, RHJ_E_INVALID, "rhj_set_option: null argument");
     const std::string n(name);
     if (n == "join.big_tables" && value >= -1 && value <= 1) { ctx->opt_big_tables = (int)value; return RHJ_OK; }
-    if (n == "join.big_kernel" && (value == -1 || value == JK_BKT_BIG || value == JK_CT || value == JK_CT_HALF)) {
+    if (n == "join.big_kernel" && (value == -1 || (value >= JK_BKT_BIG && value <= JK_CT_HALF_WIDE))) {
         ctx->opt_big_kernel = (int)value;
         return RHJ_OK;
     }

@@ -94,7 +94,7 @@ bool fused_two_pass_ok(int b1, int b2);
 // bucket-join kernels: JK_BKT partitions that fit one 4224-tuple table (two workgroups per CU); JK_BKT_BIG 8448-tuple
 // chunks, probe side re-read per chunk (any radix plan); JK_CT compact 8-byte entries, both sides read once
 // (plans that remove >= 16 payload bits)
-enum JoinKernel { JK_BKT = 0, JK_BKT_BIG = 1, JK_CT = 2, JK_CT_HALF = 3 };
+enum JoinKernel { JK_BKT = 0, JK_BKT_BIG = 1, JK_CT = 2, JK_CT_HALF = 3, JK_CT_WIDE = 4, JK_CT_HALF_WIDE = 5 };   // _WIDE: 20 probe slots per thread (narrow format only)
 u32 join_probe_split(int kind);      // probe tuples per task the kernel holds at most (0: no limit of its own)
 u32 join_table_tuples(int kind);     // build tuples per LDS table
 int join_ct_min_radix_bits();
@@ -117,7 +117,12 @@ constexpr int RHJ_RETRY_WIDE = 1000;                    // internal: join_phase 
 constexpr u64 NARROW_MIN_TUPLES = 1024;                 // 12 n + 256 <= 16 n
 constexpr u64 NARROW_AUTO_MIN_TUPLES = 8000000;         // automatic choice: larger side at least this ([measured] 4M: 0.45 ms
                                                         // either way; 16M ... 256M: 5-8 % faster narrow; 10^9: 19 %)
-bool narrow_pass_ok(int bits);
+bool narrow_pass_ok(int bits);                          // the 32-tuple-line geometry: <= 8 bits
+bool narrow_pass9_ok(int bits);                         // ... or the 16-tuple-line geometry: <= 9 bits
+void launch_hist_units_narrow(hipStream_t st, const void *d_inP, const PassGeom &g, const u64 *d_seg_start,
+                              const u32 *d_unit_start, u32 *d_unit_hist);
+void launch_scatter_units_narrow_any(hipStream_t st, const void *d_in, const u32 *d_inK, void *d_outP, u32 *d_outK, const PassGeom &g,
+                                     const u64 *d_seg_start, const u32 *d_unit_start, const u64 *d_unit_base, u32 *d_overflow);
 void launch_scatter_units_narrow(hipStream_t st, const void *d_in, void *d_out, u64 n, const PassGeom &g,
                                  const u64 *d_seg_start, const u32 *d_unit_start, const u64 *d_unit_base, u32 *d_overflow,
                                  u64 key_base = 0);

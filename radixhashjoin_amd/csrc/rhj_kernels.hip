@@ -180,6 +180,37 @@ __global__ void __launch_bounds__(1024) k_make_units(const u64 *__restrict__ seg
 // over a row range.  16 B/lane coalesced loads (the rowID rides along in the same 128 B line),
 // LDS histogram per workgroup, one flush per unit.
 // ------------------------------------------------------------------------------------------------
+// the same over a payload array (a narrow relation: 8 B/tuple), 8 loads in flight per lane
+__global__ void __launch_bounds__(PART_THREADS)
+k_hist_units_n(const u64 *__restrict__ inP, const u64 *__restrict__ seg_start, const u32 *__restrict__ unit_start,
+               u32 nseg, u64 L, int shift, int bits, u32 *__restrict__ unit_hist)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    u32 *cnt = reinterpret_cast<u32 *>(smem);
+    const u32 nbins = 1u << bits, mask = nbins - 1, u = blockIdx.x;
+    if (u >= unit_start[nseg]) return;
+    u32 lo = 0, hi = nseg;                              // find_segment (defined below)
+    while (hi - lo > 1) { const u32 mid = (lo + hi) >> 1; if (unit_start[mid] <= u) lo = mid; else hi = mid; }
+    const u32 s = lo;
+    const u64 beg = seg_start[s] + (u64)(u - unit_start[s]) * L;
+    const u64 send = seg_start[s + 1];
+    const u64 end = (beg + L < send) ? beg + L : send;
+    for (u32 b = threadIdx.x; b < nbins; b += PART_THREADS) cnt[b] = 0;
+    __syncthreads();
+    u64 i = beg + threadIdx.x;
+    for (; i + 7ull * PART_THREADS < end; i += 8ull * PART_THREADS) {
+        u64 v[8];
+#pragma unroll
+        for (int k = 0; k < 8; k++) v[k] = inP[i + (u64)k * PART_THREADS];
+#pragma unroll
+        for (int k = 0; k < 8; k++) atomicAdd(&cnt[(u32)(v[k] >> shift) & mask], 1u);
+    }
+    for (; i < end; i += PART_THREADS) atomicAdd(&cnt[(u32)(inP[i] >> shift) & mask], 1u);
+    __syncthreads();
+    u32 *out = unit_hist + (u64)u * nbins;
+    for (u32 b = threadIdx.x; b < nbins; b += PART_THREADS) out[b] = cnt[b];
+}
+
 __device__ __forceinline__ void
 dev_hist_units(const Tup *__restrict__ in, const u64 *__restrict__ seg_start, const u32 *__restrict__ unit_start,
                u32 nseg, u64 L, int shift, int bits, u32 *__restrict__ unit_hist, const u32 u, u64 *__restrict__ minmax = nullptr)
@@ -904,7 +935,11 @@ __global__ void __launch_bounds__(THREADS) k_scatter_wc2(PassPair a, int shift, 
 // staging and carry live in LDS as two arrays (8 B + 4 B per slot); one workgroup of 1024 threads per CU.
 //   IN_NARROW: the input is already narrow (pass 2 of a plan whose pass 1 wrote narrow).
 // ------------------------------------------------------------------------------------------------
+// Two geometries: <GR = 32, TPT = 4> for passes of <= 8 bits (above), and <GR = 16, TPT = 3> for 9-bit passes (plans of 17-18
+// bits, beyond 1.1 * 10^9 tuples per side): 512 carry lines of 16 tuples (one payload line + half a rowID line: 0.125 lines per
+// tuple, what the 16-byte scatter pays) = 96 KiB + a 3072-slot stage = 152 KiB of LDS.
 constexpr int WN_THREADS = 1024, WN_TPT = 4, WN_GR = 32, WN_MAX_BITS = 8;
+constexpr int WN9_TPT = 3, WN9_GR = 16, WN9_MAX_BITS = 9;
 
 // key_base (16-byte input): the rowID stored is key - key_base (a shard of a range-sharded relation sends rowIDs local to
 //   the shard; the receiver adds the sender's base again in the join, see WnTag).
@@ -913,7 +948,7 @@ constexpr int WN_THREADS = 1024, WN_TPT = 4, WN_GR = 32, WN_MAX_BITS = 8;
 //   low tag.bits bits of a payload -- constant inside the partition from here on, hence dead -- are replaced by that
 //   sender number, which the join kernels turn back into a global rowID (row0[sender] + local rowID).
 
-template <bool IN_NARROW>
+template <bool IN_NARROW, int GR_ = WN_GR, int TPT_ = WN_TPT>
 __global__ void __launch_bounds__(WN_THREADS)
 k_scatter_wcn(const Tup *__restrict__ in, const u64 *__restrict__ inP, const u32 *__restrict__ inK,
               u64 *__restrict__ outP, u32 *__restrict__ outK, const u64 *__restrict__ seg_start,
@@ -924,7 +959,7 @@ k_scatter_wcn(const Tup *__restrict__ in, const u64 *__restrict__ inP, const u32
     // a rowID that does not fit 32 bits has been seen (by the histogram kernel or by an earlier workgroup of this pass):
     // the join is going to repeat itself in the 16-byte format, nothing written from here on will be read
     if (overflow != nullptr && __builtin_nontemporal_load(overflow) != 0) return;
-    constexpr int THREADS = WN_THREADS, TPT = WN_TPT, TILE = THREADS * TPT, GR = WN_GR;
+    constexpr int THREADS = WN_THREADS, TPT = TPT_, TILE = THREADS * TPT, GR = GR_;
     constexpr u64 GM = GR - 1;
     using KeyT = typename std::conditional<IN_NARROW, u32, u64>::type;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -1586,6 +1621,10 @@ constexpr int CT_THREADS = 1024, CT_CHUNK = 17920, CT_BUCKET_BITS = 13, CT_EPT =
 // with the partition (every slot row is walked), so the full-size geometry is 2-3x too expensive there (measured at
 // 3 * 10^8: 8.9 ms against 5.1 ms for the chunked 16-byte-entry kernel).
 constexpr int CTH_THREADS = 512, CTH_CHUNK = 8960, CTH_BUCKET_BITS = 12;
+// ... and with 20 probe slots per thread instead of 16 (narrow format only; 12 spilled VGPRs): partitions whose probe side is
+// just beyond one 16-slot task (2.2 * 10^9 tuples under 17 or 18 bits: 16.8 K / 8.4 K per partition) would otherwise be cut into
+// two tasks that both build the whole table
+constexpr int CT_EPT_WIDE = 20;
 constexpr u32 CT_NONE = 0xFFFFu;
 constexpr int CT_MIN_RADIX_BITS = 16;       // keys must fit 48 bits
 constexpr u32 CT_MASK_BITS = 16;            // a probe records its matches as a bit mask over a bucket of at most this many entries
@@ -1996,10 +2035,10 @@ static size_t wc_lds_bytes(int bits, int threads)
     return (size_t)threads * WC_TPT * 16 + nbins * (128 + 8 + 8 + 8 + 4 + 4 + 4 + 4) + 16 + (size_t)(threads / 64) * 4;
 }
 
-static size_t wn_lds_bytes(int bits)
+static size_t wn_lds_bytes(int bits, int gr = WN_GR, int tpt = WN_TPT)
 {
     const size_t nbins = (size_t)1 << bits;
-    return ((size_t)WN_THREADS * WN_TPT + nbins * WN_GR) * 12 + nbins * (8 + 8 + 8 + 4 + 4 + 4 + 4) + 16 + (size_t)(WN_THREADS / 64) * 4;
+    return ((size_t)WN_THREADS * tpt + nbins * gr) * 12 + nbins * (8 + 8 + 8 + 4 + 4 + 4 + 4) + 16 + (size_t)(WN_THREADS / 64) * 4;
 }
 
 static int wc_threads_for(int bits)
@@ -2012,10 +2051,15 @@ static int wc_threads_for(int bits)
 constexpr int BJ2_THREADS = 1024, BJ2_CHUNK = 8448, BJ2_BUCKET_BITS = 12, BJ2_EPT = 4;
 
 // probe tuples per task / build tuples per table of each join kernel (host plan)
-u32 join_probe_split(int kind) { return kind == JK_CT ? (u32)(CT_THREADS * CT_EPT) : kind == JK_CT_HALF ? (u32)(CTH_THREADS * CT_EPT) : 0u; }
+u32 join_probe_split(int kind)
+{
+    return kind == JK_CT ? (u32)(CT_THREADS * CT_EPT) : kind == JK_CT_HALF ? (u32)(CTH_THREADS * CT_EPT) :
+           kind == JK_CT_WIDE ? (u32)(CT_THREADS * CT_EPT_WIDE) : kind == JK_CT_HALF_WIDE ? (u32)(CTH_THREADS * CT_EPT_WIDE) : 0u;
+}
 u32 join_table_tuples(int kind)
 {
-    return kind == JK_CT ? (u32)CT_CHUNK : kind == JK_CT_HALF ? (u32)CTH_CHUNK : kind == JK_BKT_BIG ? (u32)BJ2_CHUNK : (u32)BJ_CHUNK;
+    return kind == JK_CT || kind == JK_CT_WIDE ? (u32)CT_CHUNK : kind == JK_CT_HALF || kind == JK_CT_HALF_WIDE ? (u32)CTH_CHUNK :
+           kind == JK_BKT_BIG ? (u32)BJ2_CHUNK : (u32)BJ_CHUNK;
 }
 int join_ct_min_radix_bits() { return CT_MIN_RADIX_BITS; }
 
@@ -2079,11 +2123,15 @@ static void allow_big_lds()
     SET_LDS((k_join_ct<CT_THREADS, CT_CHUNK, CT_BUCKET_BITS, CT_EPT, true, false>), ct_lds_bytes());
     SET_LDS((k_join_ct<CT_THREADS, CT_CHUNK, CT_BUCKET_BITS, CT_EPT, false, true>), ct_lds_bytes());
     SET_LDS((k_join_ct<CTH_THREADS, CTH_CHUNK, CTH_BUCKET_BITS, CT_EPT, false, true>), ct_lds_bytes(CTH_THREADS, CTH_CHUNK, CTH_BUCKET_BITS));
+    SET_LDS((k_join_ct<CT_THREADS, CT_CHUNK, CT_BUCKET_BITS, CT_EPT_WIDE, false, true>), ct_lds_bytes());
+    SET_LDS((k_join_ct<CTH_THREADS, CTH_CHUNK, CTH_BUCKET_BITS, CT_EPT_WIDE, false, true>), ct_lds_bytes(CTH_THREADS, CTH_CHUNK, CTH_BUCKET_BITS));
     SET_LDS((k_join_bkt<BJ_THREADS, BJ_CHUNK, BJ_BUCKET_BITS, BJ_EPT, false, true, true>), bj_lds_bytes(BJ_THREADS, BJ_CHUNK, BJ_BUCKET_BITS));
     SET_LDS(k_scatter_wc_n<WC_THREADS>, wc_lds_bytes(WC_MAX_BITS, WC_THREADS));
     SET_LDS(k_scatter_wc_n<WC_THREADS_SMALL>, wc_lds_bytes(WC_MAX_BITS, WC_THREADS_SMALL));
     SET_LDS(k_scatter_wcn<false>, wn_lds_bytes(WN_MAX_BITS));
     SET_LDS(k_scatter_wcn<true>, wn_lds_bytes(WN_MAX_BITS));
+    SET_LDS((k_scatter_wcn<false, WN9_GR, WN9_TPT>), wn_lds_bytes(WN9_MAX_BITS, WN9_GR, WN9_TPT));
+    SET_LDS((k_scatter_wcn<true, WN9_GR, WN9_TPT>), wn_lds_bytes(WN9_MAX_BITS, WN9_GR, WN9_TPT));
     });
 }
 
@@ -2103,6 +2151,14 @@ void launch_hist_units(hipStream_t st, const void *d_in, const PassGeom &g, cons
     if (g.max_units == 0) return;
     hipLaunchKernelGGL(k_hist_units, dim3(g.max_units), dim3(PART_THREADS), ((size_t)4 << g.bits), st,
                        (const Tup *)d_in, d_seg_start, d_unit_start, g.nseg, g.L, g.shift, g.bits, d_unit_hist, d_minmax);
+}
+
+void launch_hist_units_narrow(hipStream_t st, const void *d_inP, const PassGeom &g, const u64 *d_seg_start,
+                              const u32 *d_unit_start, u32 *d_unit_hist)
+{
+    if (g.max_units == 0) return;
+    hipLaunchKernelGGL(k_hist_units_n, dim3(g.max_units), dim3(PART_THREADS), ((size_t)4 << g.bits), st, (const u64 *)d_inP,
+                       d_seg_start, d_unit_start, g.nseg, g.L, g.shift, g.bits, d_unit_hist);
 }
 
 void launch_scan_units(hipStream_t st, const PassGeom &g, const u64 *d_seg_start, const u32 *d_unit_start,
@@ -2262,6 +2318,7 @@ void launch_scatter_ranges_n2a(hipStream_t st, const void *d_in, void *d_out, u6
 // Narrow-format scatters (k_scatter_wcn).  A narrow relation of n tuples lives in one buffer of >= 16 n bytes: payloads
 // (u64) at offset 0, rowIDs (u32) at narrow_k_offset(n).
 bool narrow_pass_ok(int bits) { return bits >= 1 && bits <= WN_MAX_BITS; }
+bool narrow_pass9_ok(int bits) { return bits >= 1 && bits <= WN9_MAX_BITS; }
 
 void launch_scatter_units_narrow(hipStream_t st, const void *d_in, void *d_out, u64 n, const PassGeom &g,
                                  const u64 *d_seg_start, const u32 *d_unit_start, const u64 *d_unit_base, u32 *d_overflow,
@@ -2273,6 +2330,28 @@ void launch_scatter_units_narrow(hipStream_t st, const void *d_in, void *d_out, 
                        (const u64 *)nullptr, (const u32 *)nullptr, (u64 *)d_out,
                        (u32 *)((unsigned char *)d_out + narrow_k_offset(n)), d_seg_start, d_unit_start, g.nseg, g.L, g.shift,
                        g.bits, d_unit_base, (const u64 *)nullptr, 0u, d_overflow, key_base, WnTag{1u, 1u, 0u});
+}
+
+// One narrow-output pass over segments cut into units (run_pass form): 16-byte or narrow input, <= 8 bits (32-tuple lines)
+// or 9 bits (16-tuple lines).  d_inK: rowIDs of a narrow input.
+void launch_scatter_units_narrow_any(hipStream_t st, const void *d_in, const u32 *d_inK, void *d_outP, u32 *d_outK, const PassGeom &g,
+                                     const u64 *d_seg_start, const u32 *d_unit_start, const u64 *d_unit_base, u32 *d_overflow)
+{
+    if (g.max_units == 0) return;
+    allow_big_lds();
+    const bool in_narrow = d_inK != nullptr;
+    const WnTag notag{1u, 1u, 0u};
+#define WCN_ARGS (const Tup *)(in_narrow ? nullptr : d_in), (const u64 *)(in_narrow ? d_in : nullptr), d_inK, (u64 *)d_outP, d_outK,    \
+                 d_seg_start, d_unit_start, g.nseg, g.L, g.shift, g.bits, d_unit_base, (const u64 *)nullptr, 0u, d_overflow, (u64)0, notag
+    if (g.bits <= WN_MAX_BITS) {
+        if (in_narrow) hipLaunchKernelGGL(k_scatter_wcn<true>, dim3(g.max_units), dim3(WN_THREADS), wn_lds_bytes(g.bits), st, WCN_ARGS);
+        else hipLaunchKernelGGL(k_scatter_wcn<false>, dim3(g.max_units), dim3(WN_THREADS), wn_lds_bytes(g.bits), st, WCN_ARGS);
+    } else {
+        const size_t lds = wn_lds_bytes(g.bits, WN9_GR, WN9_TPT);
+        if (in_narrow) hipLaunchKernelGGL((k_scatter_wcn<true, WN9_GR, WN9_TPT>), dim3(g.max_units), dim3(WN_THREADS), lds, st, WCN_ARGS);
+        else hipLaunchKernelGGL((k_scatter_wcn<false, WN9_GR, WN9_TPT>), dim3(g.max_units), dim3(WN_THREADS), lds, st, WCN_ARGS);
+    }
+#undef WCN_ARGS
 }
 
 // explicit unit ranges [d_rng[u], d_rng[u+1]); tag_groups / tag_div != 0: the low TAG_BITS bits of every payload written are
@@ -2344,12 +2423,14 @@ void launch_join(hipStream_t st, const void *d_R, const u64 *d_startR, const voi
 #define LAUNCH_BKT_N(TG) hipLaunchKernelGGL((k_join_bkt<BJ_THREADS, BJ_CHUNK, BJ_BUCKET_BITS, BJ_EPT, false, true, TG>), dim3(grid), \
             dim3(BJ_THREADS), bj_lds_bytes(BJ_THREADS, BJ_CHUNK, BJ_BUCKET_BITS), st, nR, nS, d_tasks, d_ntasks, radix_bits, o,       \
             out_capacity, d_out_count, DirectJoin{}, d_tag_base, d_skip)
-#define LAUNCH_CT_N(T, C, B) hipLaunchKernelGGL((k_join_ct<T, C, B, CT_EPT, false, true>), dim3(grid), dim3(T),                      \
+#define LAUNCH_CT_N(T, C, B, E) hipLaunchKernelGGL((k_join_ct<T, C, B, E, false, true>), dim3(grid), dim3(T),                        \
             ct_lds_bytes(T, C, B), st, nR, nS, d_tasks, d_ntasks, radix_bits, o, out_capacity, d_out_count, (u64 *)nullptr, 0u, d_skip)
         const bool tg = d_tag_base != nullptr;                              // sender tags: the one-table kernel only (the host sees to it)
         if (kind == JK_BKT) { if (tg) LAUNCH_BKT_N(true); else LAUNCH_BKT_N(false); }
-        else if (kind == JK_CT_HALF) LAUNCH_CT_N(CTH_THREADS, CTH_CHUNK, CTH_BUCKET_BITS);
-        else LAUNCH_CT_N(CT_THREADS, CT_CHUNK, CT_BUCKET_BITS);             // JK_CT (the host never asks for another kind here)
+        else if (kind == JK_CT_HALF) LAUNCH_CT_N(CTH_THREADS, CTH_CHUNK, CTH_BUCKET_BITS, CT_EPT);
+        else if (kind == JK_CT_HALF_WIDE) LAUNCH_CT_N(CTH_THREADS, CTH_CHUNK, CTH_BUCKET_BITS, CT_EPT_WIDE);
+        else if (kind == JK_CT_WIDE) LAUNCH_CT_N(CT_THREADS, CT_CHUNK, CT_BUCKET_BITS, CT_EPT_WIDE);
+        else LAUNCH_CT_N(CT_THREADS, CT_CHUNK, CT_BUCKET_BITS, CT_EPT);     // JK_CT (the host never asks for another kind here)
 #undef LAUNCH_BKT_N
 #undef LAUNCH_CT_N
         return;

@@ -18,12 +18,12 @@ from radixhashjoin_amd import Engine, Opts
 from radixhashjoin_amd.binding import GEN_CONST, GEN_R, GEN_S_UNIFORM, GEN_S_ZIPF
 
 pytestmark = pytest.mark.gpu
-BKT_BIG, CT, CT_HALF = 1, 2, 3
+BKT_BIG, CT, CT_HALF, CT_WIDE, CT_HALF_WIDE = 1, 2, 3, 4, 5
 
 
-@pytest.fixture(scope="module", params=[(BKT_BIG, 0), (CT, 0), (CT_HALF, 0), (CT, 1), (CT, 2), (CT_HALF, 2)],
+@pytest.fixture(scope="module", params=[(BKT_BIG, 0), (CT, 0), (CT_HALF, 0), (CT, 1), (CT, 2), (CT_HALF, 2), (CT_WIDE, 2), (CT_HALF_WIDE, 2)],
                 ids=["bkt_big", "compact_table", "compact_table_half", "compact_table_narrow1", "compact_table_narrow2",
-                     "compact_table_half_narrow2"])
+                     "compact_table_half_narrow2", "compact_table_20slots_narrow2", "compact_table_half_20slots_narrow2"])
 def big(request):
     e = Engine(0)
     e.set_option("join.big_tables", 1)
@@ -36,7 +36,9 @@ def big(request):
 
 def used_format(engine, plan, wide_rowids=False):
     """the format the last join ran in: the requested narrow level under a fused 8+8 plan, else 16-byte tuples"""
-    exp = engine.narrow if (plan.passes, plan.bits1, plan.bits2) == (2, 8, 8) and not wide_rowids else 0
+    fused = (plan.passes, plan.bits1, plan.bits2) == (2, 8, 8)
+    deep = plan.passes == 2 and plan.bits1 + plan.bits2 > 16 and max(plan.bits1, plan.bits2) <= 9      # 17-18 bits: level 2 only
+    exp = 0 if wide_rowids else engine.narrow if fused else 2 if deep and engine.narrow == 2 else 0
     assert engine.info("last.narrow") == exp
     engine.set_option("partition.narrow", engine.narrow)        # re-arm after a fallback
 
@@ -69,6 +71,7 @@ def check(engine, oracle, R, S, plan, wide_rowids=False):
                                         (200_000, 50_000, 4),        # build on S (the smaller bucket), pairs stay (rowR,rowS)
                                         (17_920, 16_384, 1),         # exactly one table, exactly one task
                                         (17_921, 16_385, 1),         # one tuple beyond each
+                                        (17_000, 20_480, 1), (8_900, 10_241, 1),   # the 20-slot tasks: exactly one, one beyond
                                         (300_000, 300_000, 1500)])   # 200-tuple partitions through the same kernels
 def test_pkfk_16_bit_plan(big, oracle, nR, nS, nlow):
     rng = np.random.default_rng(nR + nS)
@@ -79,10 +82,29 @@ def test_pkfk_16_bit_plan(big, oracle, nR, nS, nlow):
     check(big, oracle, R, S, Opts(2, 8, 8))
 
 
-@pytest.mark.parametrize("plan", [Opts(2, 8, 8), Opts(2, 9, 9), Opts(2, 10, 10)])
+@pytest.mark.parametrize("plan", [Opts(2, 8, 8), Opts(2, 9, 9), Opts(2, 9, 8), Opts(2, 8, 9), Opts(2, 10, 10)])
 def test_generated_inputs_forced_big(big, oracle, plan):
     R, S = oracle.gen_R(400_000), oracle.gen_S_counter(700_000, 400_000, 7)
     check(big, oracle, R, S, plan)
+
+
+@pytest.mark.parametrize("plan", [Opts(2, 9, 8), Opts(2, 9, 9)])
+def test_17_and_18_bit_plans_narrow(big, oracle, plan):
+    """plans beyond 16 bits (what 1.1 - 4.4 * 10^9 tuples per side get): two narrow passes with separate histograms, the 9-bit
+    ones with 16-tuple carry lines; large partitions (few low-bit patterns), duplicates, unmatched probes, and the fall-back
+    when a rowID does not fit 32 bits"""
+    rng = np.random.default_rng(plan.bits2)
+    tb = plan.bits1 + plan.bits2
+    nR, nS, nlow = 70_000, 160_000, 3
+    rv = rng.permutation(1 << 22)[:nR].astype(np.uint64)
+    lows = np.random.default_rng(nlow).permutation(1 << tb)[:nlow].astype(np.uint64)
+    R = rel(rng, nR, (rv << np.uint64(tb)) | lows[(rv % np.uint64(nlow)).astype(np.int64)])
+    S = rel(rng, nS, R["payload"][rng.integers(0, nR, nS)], key0=(1 << 32) - nS)
+    S["payload"][::97] ^= np.uint64(1 << 50)
+    check(big, oracle, R, S, plan)
+    check(big, oracle, S, R, plan)
+    R["key"][4_321] = np.uint64(1 << 33)
+    check(big, oracle, R, S, plan, wide_rowids=True)
 
 
 def test_duplicates_on_both_sides(big, oracle):
@@ -200,6 +222,30 @@ def test_narrow_format_with_the_one_table_join(engine, oracle, plan, narrow):
             engine.set_option("partition.narrow", narrow)
     finally:
         engine.set_option("partition.narrow", -1)
+
+
+@pytest.mark.parametrize("n,kind", [(1_500_000_000, GEN_S_UNIFORM), (1_500_000_000, GEN_S_ZIPF), (2_200_000_000, GEN_S_UNIFORM)])
+def test_beyond_the_16_bit_plans_count_and_checksum(engine, n, kind):
+    """1.5 and 2.2 * 10^9 tuples per side under the automatic plan (17 and 18 radix bits, narrow format): exact count and
+    checksum of the pair set against the closed form"""
+    from radixhashjoin_amd.binding import plan as resolve
+    free, _ = engine.mem_info()
+    if free < 16 * n * 6.2:
+        pytest.skip("not enough free HBM")
+    p = resolve(n, n)
+    assert (p.passes, p.bits1, p.bits2) == (2, 9, 8)                          # 17 bits up to 2.2 * 10^9, 18 beyond
+    dR, dS, dO = engine.alloc(16 * n), engine.alloc(16 * n), engine.alloc(16 * n)
+    engine.generate(GEN_R, dR, n, 0, n)
+    engine.generate(kind, dS, n, 0, n, seed=42, theta_milli=900)
+    exp_n, exp_c = engine.expected_pkfk(dS, n)
+    try:
+        assert engine.join_dev(dR, n, dS, n, dO, n) == exp_n == n
+        assert engine.pairs_checksum(dO, n) == exp_c
+        assert engine.info("last.narrow") == 2
+    finally:
+        for b in (dR, dS, dO):
+            b.free()
+        engine.release_workspace()
 
 
 @pytest.mark.parametrize("kind,plan,narrow", [(GEN_S_UNIFORM, Opts(2, 8, 8), -1), (GEN_S_ZIPF, Opts(2, 8, 8), -1),

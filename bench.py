@@ -154,6 +154,30 @@ def extras(eng, torch, dev, steps, which="all"):
     eng.release_workspace()
     torch.cuda.empty_cache()
 
+    # beyond the 16-bit plans (the engine's own scaling axis; the reference has one fixed 8-bit pass, Result.cpp:5,91):
+    # 1.5 and 2.2 * 10^9 tuples per side under the automatic plan (17 bits = 9+8, narrow format), HBM permitting
+    from radixhashjoin_amd.binding import plan as rhj_plan
+    for n, kinds in ((1_500_000_000, (("uniform", GEN_S_UNIFORM), ("zipf0.9", GEN_S_ZIPF))), (2_200_000_000, (("uniform", GEN_S_UNIFORM),))):
+        free, _ = eng.mem_info()
+        if which != "all" or free < 16 * n * 6.3:
+            continue
+        R = torch.empty((n, 2), dtype=torch.int64, device=dev)
+        S = torch.empty((n, 2), dtype=torch.int64, device=dev)
+        out = torch.empty((n + 1024, 2), dtype=torch.int64, device=dev)
+        eng.generate(GEN_R, R, n, D=n)
+        p_ = rhj_plan(n, n)
+        for name, kind in kinds:
+            eng.generate(kind, S, n, D=n, seed=42, theta_milli=900)
+            exp = eng.expected_pkfk(S, n)
+            cnt, sec = timed_join(R, S, n, out, None, 3)
+            res[f"{n / 1e9:.1f}Bx{n / 1e9:.1f}B_{name}_auto"] = {
+                "plan": f"{p_.passes}-pass ({p_.bits1}+{p_.bits2} bit)", "ms": sec * 1e3, "tuples_per_s": 2 * n / sec,
+                "narrow": eng.info("last.narrow"), "join_kernel": eng.info("last.join_kernel"),
+                "verified": (cnt, eng.pairs_checksum(out, cnt)) == exp}
+        del R, S, out
+        eng.release_workspace()
+        torch.cuda.empty_cache()
+
     # the drop-in as the reference calls it: host AoS in, one malloc'd result page out (PCIe inclusive, pageable memory)
     n = 128_000_000 if which == "all" else 16_000_000
     Rh, Sh = host_inputs(n, rhj.TUPLE)

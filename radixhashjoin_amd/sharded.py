@@ -78,7 +78,7 @@ def _u64(x):
 
 class ShardedJoin:
     def __init__(self, engine, group=None, local_opts=None, owner_shift=OWNER_SHIFT_DEFAULT, fine_bits=None,
-                 balance=True, narrow=True, bind_stream=True):
+                 balance=True, narrow=True, bind_stream=True, force_exchange=False):
         self.engine = engine
         self.group = group if group is not None else dist.group.WORLD
         self.world = dist.get_world_size(self.group)
@@ -95,6 +95,8 @@ class ShardedJoin:
         self.local_opts = local_opts
         self.narrow = narrow                 # False: always exchange 16-byte tuples
         self.bind_stream = bind_stream       # the engine launches on torch's current stream (no fences needed)
+        self.force_exchange = force_exchange # world == 1: run the whole schedule anyway (collectives with oneself): the
+        #                                      one-GPU box's way of executing the RCCL code path of a multi-GPU job
         self.collect_timings = False         # True: sum the engine's per-kernel HIP-event timings over the calls of a join
         #                                      (synchronises after every engine call: for profiling steps, not timed ones)
         self.kernel_ms = {}
@@ -112,7 +114,7 @@ class ShardedJoin:
         (count, [count,2] tensor of {rowR,rowS}, global rowIDs)."""
         dev = R.device
         self._bind(dev)
-        if self.world == 1:
+        if self.world == 1 and not self.force_exchange:
             return self._local_join_whole(R, nR, S, nS, out)
         eng = self.engine
         can_narrow = self.narrow and hasattr(eng, "shard_stats") and self.world <= MAX_NARROW_WORLD

@@ -22,7 +22,8 @@ def pytest_sessionstart(session):
     need = [os.path.join(ROOT, "radixhashjoin_amd", "librhj_hip.so"), os.path.join(ROOT, "oracle", "liborc.so"),
             os.path.join(ROOT, "radixhashjoin_amd", "host", "join_gpu"),
             os.path.join(ROOT, "radixhashjoin_amd", "host", "host_driver"),
-            os.path.join(ROOT, "radixhashjoin_amd", "host", "query_unit")]
+            os.path.join(ROOT, "radixhashjoin_amd", "host", "query_unit"),
+            os.path.join(ROOT, "radixhashjoin_amd", "host", "sharded_host")]
     if not all(os.path.exists(p) for p in need):
         import __graft_entry__
         __graft_entry__.build()

@@ -96,3 +96,61 @@ def test_sharded_join_real_engine(world, n_per_rank, D, zipf, opts, fmt):
     assert used == fmt
     if zipf:
         assert imbalance <= 1.3, imbalance
+
+
+def rccl_worker(port, n, D, opts, mode_rows, q):
+    """ONE rank over the real RCCL backend ("nccl"): the whole sharded schedule with the collectives addressed to oneself --
+    device all_gather of the count matrix, asynchronous all_to_all_single of int64 payloads and int32 rowIDs, work.wait()
+    on the shared stream -- i.e. the torch.distributed / RCCL calls an 8-GPU job makes, on the one GPU a box has."""
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    import torch
+    import torch.distributed as dist
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_device(dev)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+    import radixhashjoin_amd as rhj
+    from radixhashjoin_amd.binding import GEN_R, GEN_S_UNIFORM
+    from radixhashjoin_amd.sharded import ShardedJoin
+    from oracle.pyoracle import Oracle, TUPLE
+    stream = torch.cuda.Stream(device=dev)
+    torch.cuda.set_stream(stream)
+    eng = rhj.Engine(0)
+    eng.set_stream(stream.cuda_stream)
+    R = torch.empty((n, 2), dtype=torch.int64, device=dev)
+    S = torch.empty((n, 2), dtype=torch.int64, device=dev)
+    eng.generate(GEN_R, R, n, row0=mode_rows, D=D)
+    eng.generate(GEN_S_UNIFORM, S, n, row0=mode_rows, D=D, seed=42)
+    sj = ShardedJoin(eng, dist.group.WORLD, local_opts=rhj.Opts(*opts), force_exchange=True)
+    cnt, out = sj.join(R, n, S, n)
+    torch.cuda.synchronize()
+    pairs = out[:cnt].cpu().numpy().view(np.uint64)
+    o = Oracle()
+    def tup(t):
+        a = t.cpu().numpy().view(np.uint64)
+        x = np.empty(len(a), dtype=TUPLE)
+        x["key"], x["payload"] = a[:, 0], a[:, 1]
+        return x
+    exp = o.join(tup(R), tup(S))
+    a = pairs[np.lexsort((pairs[:, 1], pairs[:, 0]))]
+    e = np.stack([exp["keyR"], exp["keyS"]], axis=1)
+    e = e[np.lexsort((e[:, 1], e[:, 0]))]
+    q.put((len(pairs), len(exp), bool(np.array_equal(a, e)), sj.stats["format"], sj.stats.get("rowid_mode"), sj.transport()))
+    eng.close()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("n,D,opts,row0,mode", [(600_000, 200_000, (2, 5, 5), 0, "plain"),             # rowIDs < 2^32
+                                                (600_000, 600_000, (2, 6, 5), 1 << 33, "tagged")])   # rowIDs beyond: sender tags
+def test_sharded_schedule_over_rccl_single_rank(n, D, opts, row0, mode):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=rccl_worker, args=(free_port(), n, D, opts, row0, q))
+    p.start()
+    got, exp, same, fmt, rowid_mode, transport = q.get(timeout=600)
+    p.join(timeout=120)
+    assert p.exitcode == 0
+    assert got == exp and same
+    assert fmt == "narrow12" and rowid_mode == mode and "RCCL" in transport

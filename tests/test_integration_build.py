@@ -59,3 +59,15 @@ def test_seam_target_builds():
     d = _defined_symbols(seam)
     assert "Result::refMultiRadixHashJoin" in d               # the CPU body is still there under another name...
     assert "Query::run_joins" in d
+
+
+def test_cpp_sharded_host_links_rccl_and_the_shard_stage_calls():
+    """radixhashjoin_amd/host/sharded_host.cpp: the multi-GPU schedule from a C++ host -- RCCL for the collectives, the
+    C-ABI for the compute (no torch, no Python)"""
+    r = subprocess.run(["make", "-s", "-C", os.path.join(ROOT, "radixhashjoin_amd", "host"), "sharded_host"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout + r.stderr
+    binary = os.path.join(ROOT, "radixhashjoin_amd", "host", "sharded_host")
+    und = _undefined_symbols(binary)
+    for sym in ("rhj_shard_stats", "rhj_shard_split", "rhj_shard_partition", "rhj_shard_join", "rhj_shard_plan",
+                "ncclAllGather", "ncclSend", "ncclRecv", "ncclGroupStart", "ncclAllReduce", "ncclCommInitRank"):
+        assert sym in und, sym

@@ -14,7 +14,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 BIN = os.path.join(ROOT, "radixhashjoin_amd", "host", "sharded_host")
 
 
-@pytest.mark.parametrize("rows,dist_", [(3_000_000, "uniform"), (20_000_000, "zipf")])
+@pytest.mark.parametrize("rows,dist_", [(12_000_000, "uniform"), (20_000_000, "zipf")])
 def test_cpp_host_runs_the_sharded_schedule_over_rccl(tmp_path, rows, dist_):
     if not os.path.exists(BIN):
         pytest.skip("sharded_host not built")

@@ -189,7 +189,9 @@ def extras(eng, torch, dev, steps, which="all"):
     sec = sorted(secs)[1]
     res[f"end_to_end_rhj_join_{n // 1_000_000}Mx{n // 1_000_000}M"] = {"ms": sec * 1e3, "tuples_per_s": 2 * n / sec, "matches": cnt,
                                             "pcie_GBps": (32.0 * n + 16.0 * cnt) / sec / 1e9, "runs_ms": [round(x * 1e3, 1) for x in secs],
-                                            "note": "H2D of both inputs from pageable memory + kernels + D2H of the result page"}
+                                            "s_chunks_pipelined": eng.info("last.pipelined"),
+                                            "note": "H2D of both inputs from pageable memory + kernels + D2H of the result page; pcie_GBps = (input + "
+                                                    "result bytes) / wall time, above one direction's wire rate when download overlaps upload"}
     del Rh, Sh
 
     # config 1's joins: the 94 multiRadixHashJoin calls the reference makes on small.work (sizes from the link-time tap,

@@ -96,7 +96,8 @@ int  rhj_set_profiling(rhj_ctx *ctx, int enabled);
  * in the 16-byte format; the next join tries the narrow format again). */
 int  rhj_set_option(rhj_ctx *ctx, const char *name, int64_t value);
 /* what the last join did: "last.narrow" (0 / 1 / 2, see above), "last.join_kernel" (0 one-table, 1 chunked, 2 / 3
- * compact table full / half size, 4 / 5 the same with 20 probe slots per thread, -1 none: direct small join or empty input) */
+ * compact table full / half size, 4 / 5 the same with 20 probe slots per thread, -1 none: direct small join or empty input), "last.pipelined" (the number
+ * of S chunks the last rhj_join streamed through the device while finished pairs travelled home; 0: the plain path) */
 int  rhj_get_info(rhj_ctx *ctx, const char *name, int64_t *value);
 int  rhj_get_timings(rhj_ctx *ctx, rhj_timings *out);
 int  rhj_sync(rhj_ctx *ctx);                             /* JobScheduler::barrier (JobScheduler.cpp:103-122) */

@@ -116,6 +116,9 @@ struct rhj_ctx {
     size_t free_bytes = 0;
     // pinned staging for host -> HBM copies of pageable caller memory (rhj_join)
     Stager *stager = nullptr;
+    unsigned char *h_counts = nullptr;     // pinned: the join counters of every S chunk of a pipelined rhj_join (64 B each)
+    std::vector<hipEvent_t> chunk_ev;
+    hipStream_t down_stream = nullptr;     // result chunks travel home while later S chunks are still on their way in
     hipStream_t copy_stream = nullptr;     // uploads of rhj_join: S travels while R is being partitioned
     hipEvent_t up_ev[2] = {nullptr, nullptr};
     // state of the last partition phase (consumed by join_phase)
@@ -125,6 +128,7 @@ struct rhj_ctx {
     int cur_radix_bits = 0;
     u32 cur_probe_split = 0;
     int last_join_kind = -1;
+    int last_pipelined = 0;            // S chunks of the last rhj_join (0: not pipelined)
     bool counters_clean = false;       // the 64-byte join counters are zero (cleared by the partition phase's first launch)
     int cur_narrow = 0;                // partitions are in the narrow {payload, rowID} format (k_scatter_wcn); 2: so was the intermediate
     DevBuf narrow_flag;                // u32: a rowID >= 2^32 met a narrow scatter -> the join re-runs in the 16-byte format
@@ -802,8 +806,11 @@ int partition_phase(rhj_ctx *ctx, const void *d_R, u64 nR, const void *d_S, u64 
 // of a tuple and rowIDs are local to it (multi-GPU receiver).  allow_direct: the boundaries are known to be {0, n}.
 int join_phase_on(rhj_ctx *ctx, const void *d_Rp, const u64 *d_psR, u64 nR, const void *d_Sp, const u64 *d_psS,
                   u64 nS, u64 nparts, int radix_bits, u32 probe_split, void *d_out, u64 cap, u64 *out_count, bool narrow = false,
-                  const u64 *d_tag_base = nullptr, bool allow_direct = true, bool check_radix = false)
+                  const u64 *d_tag_base = nullptr, bool allow_direct = true, bool check_radix = false, bool keep_count = false,
+                  bool enqueue_only = false)
 {
+    // keep_count: the result counter goes on from where the previous join on this context left it (the pairs of several joins
+    // land behind one another in d_out); enqueue_only: no read-back, the caller collects the counters itself
     if (probe_split == 0) probe_split = 32768;
     // a task addresses its build range with 32 bits; k_make_tasks reports any partition whose build side is larger
     // (counters[5], checked below) whatever the plan
@@ -818,7 +825,10 @@ int join_phase_on(rhj_ctx *ctx, const void *d_Rp, const u64 *d_psR, u64 nR, cons
     RHJCHK(ensure(ctx, ctx->counters, 64));
     u64 *d_count = (u64 *)ctx->counters.p;
     u32 *d_ntasks = (u32 *)(d_count + 1);
-    if (!ctx->counters_clean) {                      // (a paired partition pass has cleared them already)
+    if (keep_count) {
+        Span s(ctx, RHJ_K_AUX);
+        HIPCHK(ctx, hipMemsetAsync((unsigned char *)ctx->counters.p + 8, 0, 56, ctx->stream));
+    } else if (!ctx->counters_clean) {               // (a paired partition pass has cleared them already)
         Span s(ctx, RHJ_K_AUX);
         HIPCHK(ctx, hipMemsetAsync(ctx->counters.p, 0, 64, ctx->stream));
     }
@@ -848,6 +858,7 @@ int join_phase_on(rhj_ctx *ctx, const void *d_Rp, const u64 *d_psR, u64 nR, cons
         }
     }
     RHJCHK(check_launch(ctx, "join phase"));
+    if (enqueue_only) return RHJ_OK;
     u64 host[7] = {0, 0, 0, 0, 0, 0, 0};       // count, ntasks, max |R_k|, max |S_k|, (checksum scratch), oversized build side, contract
     u32 wide_rowid = 0;
     HIPCHK(ctx, hipMemcpyAsync(host, ctx->counters.p, sizeof(host), hipMemcpyDeviceToHost, ctx->stream));
@@ -892,6 +903,14 @@ int partition_and_join(rhj_ctx *ctx, const void *d_R, u64 nR, const void *d_S, u
     ctx->narrow_off_once = false;
     if (rc != RHJ_OK) { ctx->counters_clean = false; return rc; }
     return join_phase(ctx, d_out, cap, out_count);
+}
+
+// one relation under a resolved two-pass (or one-pass) plan; narrow: the level narrow_level() returned for the join
+int partition_side(rhj_ctx *ctx, const void *d_in, u64 n, const rhj_opts &plan, int narrow, void *part, u64 *ps)
+{
+    if (narrow && !narrow_fused_plan(plan)) return partition_relation_narrow2(ctx, d_in, n, plan.bits1, plan.bits2, part, ps);
+    if (narrow) return partition_relation_fused(ctx, d_in, n, plan.bits1, plan.bits2, part, ps, narrow);
+    return partition_relation(ctx, d_in, n, plan.passes, plan.bits1, plan.bits2, part, ps);
 }
 
 }  // namespace
@@ -983,6 +1002,9 @@ int rhj_release_workspace(rhj_ctx *ctx)
     ctx->free_bytes = 0;
     if (ctx->h_land) { (void)hipHostFree(ctx->h_land); ctx->h_land = nullptr; }
     stager_destroy(ctx);
+    if (ctx->h_counts) { (void)hipHostFree(ctx->h_counts); ctx->h_counts = nullptr; }
+    for (hipEvent_t e : ctx->chunk_ev) (void)hipEventDestroy(e);
+    ctx->chunk_ev.clear();
     return RHJ_OK;
 }
 
@@ -994,6 +1016,7 @@ void rhj_destroy(rhj_ctx *ctx)
     for (hipEvent_t ev : ctx->prof.pool) (void)hipEventDestroy(ev);
     for (int i = 0; i < 2; i++) if (ctx->up_ev[i]) (void)hipEventDestroy(ctx->up_ev[i]);
     if (ctx->copy_stream) (void)hipStreamDestroy(ctx->copy_stream);
+    if (ctx->down_stream) (void)hipStreamDestroy(ctx->down_stream);
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
     delete ctx;
 }
@@ -1029,6 +1052,7 @@ int rhj_get_info(rhj_ctx *ctx, const char *name, int64_t *value)
     const std::string n(name);
     if (n == "last.narrow") { *value = ctx->cur_narrow; return RHJ_OK; }
     if (n == "last.join_kernel") { *value = ctx->last_join_kind; return RHJ_OK; }
+    if (n == "last.pipelined") { *value = ctx->last_pipelined; return RHJ_OK; }
     return fail(ctx, RHJ_E_INVALID, "rhj_get_info: unknown name: " + n);
 }
 
@@ -1229,6 +1253,177 @@ int join_small_host(rhj_ctx *ctx, const rhj_tuple *R, u64 nR, const rhj_tuple *S
 
 }  // namespace
 
+namespace {
+
+// rhj_join for inputs of hundreds of MiB: PCIe is full duplex, so the call should cost about max(upload, download), not their
+// sum.  R is uploaded and partitioned once; S goes through in CHUNKS -- R join S = union of R join S_i --: while chunk i+1 is
+// being staged and uploaded, chunk i is partitioned (same radix plan) and joined against the partitioned R, its pairs landing
+// behind the earlier chunks' in the pair buffer (the result counter simply runs on), and a downloader thread brings finished
+// ranges of pairs home into the result page.  Returns RHJ_NOT_PIPELINED when the call should take the plain path instead
+// (small inputs, a rowID that does not fit the narrow format, more pairs than the optimistic page holds).
+constexpr int RHJ_NOT_PIPELINED = 1001;
+constexpr u64 PIPE_MIN_CHUNK = (u64)16 << 20;          // tuples per S chunk at least
+constexpr int PIPE_MAX_CHUNKS = 8;
+
+int join_host_pipelined(rhj_ctx *ctx, const rhj_tuple *R, u64 nR, const rhj_tuple *S, u64 nS, const rhj_opts &plan,
+                        void **out_page, u64 *out_count)
+{
+    static const bool off = getenv("RHJ_NO_PIPELINE") != nullptr;                 // tuning aid: A/B against the plain path
+    static const bool trace = getenv("RHJ_TRACE_JOIN") != nullptr;
+    int K = (int)(nS / PIPE_MIN_CHUNK < (u64)PIPE_MAX_CHUNKS ? nS / PIPE_MIN_CHUNK : (u64)PIPE_MAX_CHUNKS);
+    if (off || plan.passes != 2 || K < 2 || nR < PIPE_MIN_CHUNK / 4) return RHJ_NOT_PIPELINED;
+    const u64 chunk = ((nS + K - 1) / K + 4095) / 4096 * 4096;
+    K = (int)((nS + chunk - 1) / chunk);
+    auto now = [] { return std::chrono::steady_clock::now(); };
+    auto ms = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) {
+        return std::chrono::duration<double, std::milli>(b - a).count();
+    };
+    const auto t0 = now();
+    const u64 cap = (nR > nS ? nR : nS) + 1024;
+    PagePrefault pre;
+    pre.start((size_t)cap);
+    if (!pre.page) return RHJ_NOT_PIPELINED;
+    const int narrow = narrow_level(ctx, nR, chunk, plan);
+    const int tb = plan.bits1 + plan.bits2;
+    const size_t np = (size_t)1 << tb;
+    auto setup = [&]() -> int {
+        RHJCHK(ensure(ctx, ctx->in_R, (size_t)nR * 16));
+        RHJCHK(ensure(ctx, ctx->in_S, (size_t)nS * 16));
+        RHJCHK(ensure(ctx, ctx->part_R, (size_t)nR * 16));
+        RHJCHK(ensure(ctx, ctx->part_S, (size_t)chunk * 16));
+        RHJCHK(ensure(ctx, ctx->ps_R, (np + 1) * 8));
+        RHJCHK(ensure(ctx, ctx->ps_S, (np + 1) * 8));
+        RHJCHK(ensure(ctx, ctx->out_pairs, (size_t)cap * 16));
+        RHJCHK(ensure(ctx, ctx->counters, 64));
+        RHJCHK(ensure(ctx, ctx->narrow_flag, 64));
+        if (!ctx->copy_stream) {
+            HIPCHK(ctx, hipStreamCreateWithFlags(&ctx->copy_stream, hipStreamNonBlocking));
+            for (int i = 0; i < 2; i++) HIPCHK(ctx, hipEventCreateWithFlags(&ctx->up_ev[i], hipEventDisableTiming));
+        }
+        if (!ctx->down_stream) HIPCHK(ctx, hipStreamCreateWithFlags(&ctx->down_stream, hipStreamNonBlocking));
+        if (!ctx->h_counts) HIPCHK(ctx, hipHostMalloc((void **)&ctx->h_counts, (size_t)PIPE_MAX_CHUNKS * 128, hipHostMallocDefault));
+        while ((int)ctx->chunk_ev.size() < K) {
+            hipEvent_t e;
+            HIPCHK(ctx, hipEventCreateWithFlags(&e, hipEventDisableTiming));
+            ctx->chunk_ev.push_back(e);
+        }
+        return RHJ_OK;
+    };
+    int rc = setup();
+    if (rc != RHJ_OK) { pre.drop(); return rc; }
+    const u64 dcap = ctx->out_pairs.cap / 16 < pre.pairs ? ctx->out_pairs.cap / 16 : pre.pairs;
+    unsigned char *page = pre.page;
+
+    // downloader: finished ranges of pairs -> result page, on its own stream, while later chunks are still coming in
+    std::mutex mu;
+    std::condition_variable cv;
+    std::vector<std::pair<u64, u64>> todo;                 // (first pair, pairs)
+    bool closing = false, dl_failed = false;
+    std::thread downloader([&] {
+        (void)hipSetDevice(ctx->device);
+        pre.wait();                                        // the helper threads still WRITE into the page while they fault it in
+        for (;;) {
+            std::pair<u64, u64> job;
+            {
+                std::unique_lock<std::mutex> lk(mu);
+                cv.wait(lk, [&] { return closing || !todo.empty(); });
+                if (todo.empty()) return;
+                job = todo.front();
+                todo.erase(todo.begin());
+            }
+            hipError_t e = hipMemcpyAsync(page + 8 + job.first * 16, (const unsigned char *)ctx->out_pairs.p + job.first * 16,
+                                          (size_t)job.second * 16, hipMemcpyDeviceToHost, ctx->down_stream);
+            if (e == hipSuccess) e = hipStreamSynchronize(ctx->down_stream);
+            if (e != hipSuccess) dl_failed = true;
+        }
+    });
+    auto finish_downloader = [&] {
+        { std::lock_guard<std::mutex> lk(mu); closing = true; }
+        cv.notify_all();
+        downloader.join();
+    };
+
+    bool abandon = false;                                  // wide rowID / more pairs than the page holds: take the plain path
+    std::string errtext;
+    u64 handed = 0, count = 0;
+    int collected = 0;
+    auto collect = [&](int j) {                            // chunk j's join has finished: hand its pairs to the downloader
+        const u64 *h = (const u64 *)(ctx->h_counts + (size_t)j * 128);
+        const u32 wide = *(const u32 *)(ctx->h_counts + (size_t)j * 128 + 64);
+        if (wide || h[0] > dcap) { abandon = true; return; }
+        if (h[5]) { errtext = "a partition's build side has " + std::to_string(h[5]) + " tuples (>= 2^32): use more radix bits"; return; }
+        count = h[0];
+        ctx->last.ntasks += (u32)(h[1] & 0xffffffffu);
+        if (count > handed) {
+            { std::lock_guard<std::mutex> lk(mu); todo.emplace_back(handed, count - handed); }
+            cv.notify_all();
+            handed = count;
+        }
+    };
+    auto body = [&]() -> int {
+        ctx->cur_narrow = narrow;
+        ctx->last.passes = plan.passes;
+        ctx->last.bits1 = plan.bits1;
+        ctx->last.bits2 = plan.bits2;
+        ctx->counters_clean = false;
+        HIPCHK(ctx, hipMemsetAsync(ctx->narrow_flag.p, 0, 64, ctx->stream));
+        HIPCHK(ctx, hipMemsetAsync(ctx->counters.p, 0, 64, ctx->stream));
+        HIPCHK(ctx, hipEventRecord(ctx->up_ev[0], ctx->stream));           // (earlier work of this context may still read in_R / in_S)
+        HIPCHK(ctx, hipStreamWaitEvent(ctx->copy_stream, ctx->up_ev[0], 0));
+        RHJCHK(h2d_staged(ctx, ctx->in_R.p, R, (size_t)nR * 16, ctx->copy_stream));
+        HIPCHK(ctx, hipEventRecord(ctx->up_ev[0], ctx->copy_stream));
+        HIPCHK(ctx, hipStreamWaitEvent(ctx->stream, ctx->up_ev[0], 0));
+        RHJCHK(partition_side(ctx, ctx->in_R.p, nR, plan, narrow, ctx->part_R.p, (u64 *)ctx->ps_R.p));
+        for (int i = 0; i < K && !abandon && errtext.empty(); i++) {
+            const u64 off_i = (u64)i * chunk, n_i = nS - off_i < chunk ? nS - off_i : chunk;
+            void *d_Si = (unsigned char *)ctx->in_S.p + off_i * 16;
+            RHJCHK(h2d_staged(ctx, d_Si, S + off_i, (size_t)n_i * 16, ctx->copy_stream));
+            HIPCHK(ctx, hipEventRecord(ctx->up_ev[1], ctx->copy_stream));
+            HIPCHK(ctx, hipStreamWaitEvent(ctx->stream, ctx->up_ev[1], 0));
+            RHJCHK(partition_side(ctx, d_Si, n_i, plan, narrow, ctx->part_S.p, (u64 *)ctx->ps_S.p));
+            u64 unused = 0;
+            RHJCHK(join_phase_on(ctx, ctx->part_R.p, (const u64 *)ctx->ps_R.p, nR, ctx->part_S.p, (const u64 *)ctx->ps_S.p, n_i, np, tb,
+                                 (u32)plan.probe_split, ctx->out_pairs.p, dcap, &unused, narrow != 0, nullptr, false, false, i > 0, true));
+            HIPCHK(ctx, hipMemcpyAsync(ctx->h_counts + (size_t)i * 128, ctx->counters.p, 64, hipMemcpyDeviceToHost, ctx->stream));
+            HIPCHK(ctx, hipMemcpyAsync(ctx->h_counts + (size_t)i * 128 + 64, ctx->narrow_flag.p, 4, hipMemcpyDeviceToHost, ctx->stream));
+            HIPCHK(ctx, hipEventRecord(ctx->chunk_ev[i], ctx->stream));
+            while (collected < i && hipEventQuery(ctx->chunk_ev[collected]) == hipSuccess) collect(collected++);
+        }
+        for (; collected < K && !abandon && errtext.empty(); collected++) {
+            HIPCHK(ctx, hipEventSynchronize(ctx->chunk_ev[collected]));
+            collect(collected);
+        }
+        return RHJ_OK;
+    };
+    rc = body();
+    const auto t1 = now();
+    finish_downloader();
+    (void)hipStreamSynchronize(ctx->stream);               // nothing of this call is in flight when it returns
+    (void)hipGetLastError();
+    if (rc == RHJ_OK && !errtext.empty()) rc = fail(ctx, RHJ_E_INVALID, errtext);
+    if (rc == RHJ_OK && dl_failed) rc = fail(ctx, RHJ_E_HIP, "result copy failed");
+    if (rc != RHJ_OK || abandon || count == 0) {
+        pre.page = page;                                   // (drop() frees it)
+        pre.drop();
+        if (rc != RHJ_OK) return rc;
+        if (abandon) return RHJ_NOT_PIPELINED;
+        *out_page = nullptr;                               // no match: head stays nullptr (Result::isEmpty)
+        *out_count = 0;
+        return RHJ_OK;
+    }
+    pre.page = nullptr;                                    // the caller's now
+    ctx->last_pipelined = K;
+    memset(page, 0, 8);                                    // bucket_info::next = nullptr (Result.h:14-17)
+    if (trace)
+        fprintf(stderr, "[rhj_join pipelined %llu x %llu -> %llu, %d chunks of S] enqueued %.1f  tail (last join + download) %.1f  total %.1f ms\n",
+                (unsigned long long)nR, (unsigned long long)nS, (unsigned long long)count, K, ms(t0, t1), ms(t1, now()), ms(t0, now()));
+    *out_page = page;
+    *out_count = count;
+    return RHJ_OK;
+}
+
+}  // namespace
+
 int rhj_join(rhj_ctx *ctx, const rhj_tuple *R, uint64_t nR, const rhj_tuple *S, uint64_t nS,
              const rhj_opts *opts, void **out_page, uint64_t *out_count)
 {
@@ -1237,11 +1432,17 @@ int rhj_join(rhj_ctx *ctx, const rhj_tuple *R, uint64_t nR, const rhj_tuple *S, 
     *out_page = nullptr;
     *out_count = 0;
     prof_reset(ctx);
+    ctx->last_pipelined = 0;
     if (nR == 0 || nS == 0) return RHJ_OK;
     if (!R || !S) return fail(ctx, RHJ_E_INVALID, "null input relation");
     rhj_opts plan;
     if (resolve_plan(nR, nS, opts, &plan) != RHJ_OK) return fail(ctx, RHJ_E_INVALID, "bad rhj_opts");
     if (plan.passes == 0 && is_direct(ctx, 1, nR, nS)) return join_small_host(ctx, R, nR, S, nS, out_page, (u64 *)out_count);
+    {
+        const int prc = join_host_pipelined(ctx, R, nR, S, nS, plan, out_page, (u64 *)out_count);
+        if (prc != RHJ_NOT_PIPELINED) return prc;
+        prof_reset(ctx);
+    }
     // optimistic capacity: a foreign-key join yields about max(|R|,|S|) pairs; the count is exact
     // either way, and an overflow only repeats the join phase (partitions stay in the workspace)
     u64 cap = (nR > nS ? nR : nS) + 1024;

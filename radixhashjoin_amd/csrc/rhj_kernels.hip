@@ -935,11 +935,12 @@ __global__ void __launch_bounds__(THREADS) k_scatter_wc2(PassPair a, int shift, 
 // staging and carry live in LDS as two arrays (8 B + 4 B per slot); one workgroup of 1024 threads per CU.
 //   IN_NARROW: the input is already narrow (pass 2 of a plan whose pass 1 wrote narrow).
 // ------------------------------------------------------------------------------------------------
-// Two geometries: <GR = 32, TPT = 4> for passes of <= 8 bits (above), and <GR = 16, TPT = 3> for 9-bit passes (plans of 17-18
-// bits, beyond 1.1 * 10^9 tuples per side): 512 carry lines of 16 tuples (one payload line + half a rowID line: 0.125 lines per
-// tuple, what the 16-byte scatter pays) = 96 KiB + a 3072-slot stage = 152 KiB of LDS.
+// Two geometries: <GR = 32, 1024 threads x 4> for passes of <= 8 bits (above), and <GR = 16, 896 threads x 4> for 9-bit passes
+// (plans of 17-18 bits, beyond 1.1 * 10^9 tuples per side): 512 carry lines of 16 tuples (one payload line + half a rowID line:
+// 0.125 lines per tuple, what the 16-byte scatter pays) = 96 KiB + a 3584-slot stage = 158 KiB of LDS.
 constexpr int WN_THREADS = 1024, WN_TPT = 4, WN_GR = 32, WN_MAX_BITS = 8;
-constexpr int WN9_TPT = 3, WN9_GR = 16, WN9_MAX_BITS = 9;
+constexpr int WN9_THREADS = 896, WN9_TPT = 4, WN9_GR = 16, WN9_MAX_BITS = 9;   // 14 wavefronts x 4 tuples: a 3584-slot stage is
+                                                                                // what 160 KiB leave beside 512 x 16-tuple carry lines
 
 // key_base (16-byte input): the rowID stored is key - key_base (a shard of a range-sharded relation sends rowIDs local to
 //   the shard; the receiver adds the sender's base again in the join, see WnTag).
@@ -948,8 +949,8 @@ constexpr int WN9_TPT = 3, WN9_GR = 16, WN9_MAX_BITS = 9;
 //   low tag.bits bits of a payload -- constant inside the partition from here on, hence dead -- are replaced by that
 //   sender number, which the join kernels turn back into a global rowID (row0[sender] + local rowID).
 
-template <bool IN_NARROW, int GR_ = WN_GR, int TPT_ = WN_TPT>
-__global__ void __launch_bounds__(WN_THREADS)
+template <bool IN_NARROW, int GR_ = WN_GR, int TPT_ = WN_TPT, int THREADS_ = WN_THREADS>
+__global__ void __launch_bounds__(THREADS_)
 k_scatter_wcn(const Tup *__restrict__ in, const u64 *__restrict__ inP, const u32 *__restrict__ inK,
               u64 *__restrict__ outP, u32 *__restrict__ outK, const u64 *__restrict__ seg_start,
               const u32 *__restrict__ unit_start, u32 nseg, u64 L, int shift, int bits,
@@ -959,7 +960,7 @@ k_scatter_wcn(const Tup *__restrict__ in, const u64 *__restrict__ inP, const u32
     // a rowID that does not fit 32 bits has been seen (by the histogram kernel or by an earlier workgroup of this pass):
     // the join is going to repeat itself in the 16-byte format, nothing written from here on will be read
     if (overflow != nullptr && __builtin_nontemporal_load(overflow) != 0) return;
-    constexpr int THREADS = WN_THREADS, TPT = TPT_, TILE = THREADS * TPT, GR = GR_;
+    constexpr int THREADS = THREADS_, TPT = TPT_, TILE = THREADS * TPT, GR = GR_;
     constexpr u64 GM = GR - 1;
     using KeyT = typename std::conditional<IN_NARROW, u32, u64>::type;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -1936,8 +1937,10 @@ k_join_ct(const RelView<NARROW> R, const RelView<NARROW> S, const JoinTask *__re
                             Pair pr;
                             if (build_is_S) { pr.r = prid[k]; pr.s = br; }      // orderFlag, Result.cpp:64-68
                             else            { pr.r = br; pr.s = prid[k]; }
-                            typedef u64 u64x2 __attribute__((ext_vector_type(2)));
-                            __builtin_nontemporal_store(u64x2{pr.r, pr.s}, reinterpret_cast<u64x2 *>(out + dst));
+                            // plain (not nontemporal) stores: a wavefront's pair run continues in the next slot's store a
+                            // microsecond later; with the nt hint the shared 128 B line at the seam went to HBM twice
+                            // ([measured] WRITE_SIZE 18.32 GB per 10^9 pairs against 16.03, same kernel time within 1 %)
+                            out[dst] = pr;
                         }
                     }
                     o += (u64)__popcll(bal);
@@ -2035,10 +2038,10 @@ static size_t wc_lds_bytes(int bits, int threads)
     return (size_t)threads * WC_TPT * 16 + nbins * (128 + 8 + 8 + 8 + 4 + 4 + 4 + 4) + 16 + (size_t)(threads / 64) * 4;
 }
 
-static size_t wn_lds_bytes(int bits, int gr = WN_GR, int tpt = WN_TPT)
+static size_t wn_lds_bytes(int bits, int gr = WN_GR, int tpt = WN_TPT, int threads = WN_THREADS)
 {
     const size_t nbins = (size_t)1 << bits;
-    return ((size_t)WN_THREADS * tpt + nbins * gr) * 12 + nbins * (8 + 8 + 8 + 4 + 4 + 4 + 4) + 16 + (size_t)(WN_THREADS / 64) * 4;
+    return ((size_t)threads * tpt + nbins * gr) * 12 + nbins * (8 + 8 + 8 + 4 + 4 + 4 + 4) + 16 + (size_t)(threads / 64) * 4;
 }
 
 static int wc_threads_for(int bits)
@@ -2130,8 +2133,8 @@ static void allow_big_lds()
     SET_LDS(k_scatter_wc_n<WC_THREADS_SMALL>, wc_lds_bytes(WC_MAX_BITS, WC_THREADS_SMALL));
     SET_LDS(k_scatter_wcn<false>, wn_lds_bytes(WN_MAX_BITS));
     SET_LDS(k_scatter_wcn<true>, wn_lds_bytes(WN_MAX_BITS));
-    SET_LDS((k_scatter_wcn<false, WN9_GR, WN9_TPT>), wn_lds_bytes(WN9_MAX_BITS, WN9_GR, WN9_TPT));
-    SET_LDS((k_scatter_wcn<true, WN9_GR, WN9_TPT>), wn_lds_bytes(WN9_MAX_BITS, WN9_GR, WN9_TPT));
+    SET_LDS((k_scatter_wcn<false, WN9_GR, WN9_TPT, WN9_THREADS>), wn_lds_bytes(WN9_MAX_BITS, WN9_GR, WN9_TPT, WN9_THREADS));
+    SET_LDS((k_scatter_wcn<true, WN9_GR, WN9_TPT, WN9_THREADS>), wn_lds_bytes(WN9_MAX_BITS, WN9_GR, WN9_TPT, WN9_THREADS));
     });
 }
 
@@ -2347,9 +2350,9 @@ void launch_scatter_units_narrow_any(hipStream_t st, const void *d_in, const u32
         if (in_narrow) hipLaunchKernelGGL(k_scatter_wcn<true>, dim3(g.max_units), dim3(WN_THREADS), wn_lds_bytes(g.bits), st, WCN_ARGS);
         else hipLaunchKernelGGL(k_scatter_wcn<false>, dim3(g.max_units), dim3(WN_THREADS), wn_lds_bytes(g.bits), st, WCN_ARGS);
     } else {
-        const size_t lds = wn_lds_bytes(g.bits, WN9_GR, WN9_TPT);
-        if (in_narrow) hipLaunchKernelGGL((k_scatter_wcn<true, WN9_GR, WN9_TPT>), dim3(g.max_units), dim3(WN_THREADS), lds, st, WCN_ARGS);
-        else hipLaunchKernelGGL((k_scatter_wcn<false, WN9_GR, WN9_TPT>), dim3(g.max_units), dim3(WN_THREADS), lds, st, WCN_ARGS);
+        const size_t lds = wn_lds_bytes(g.bits, WN9_GR, WN9_TPT, WN9_THREADS);
+        if (in_narrow) hipLaunchKernelGGL((k_scatter_wcn<true, WN9_GR, WN9_TPT, WN9_THREADS>), dim3(g.max_units), dim3(WN9_THREADS), lds, st, WCN_ARGS);
+        else hipLaunchKernelGGL((k_scatter_wcn<false, WN9_GR, WN9_TPT, WN9_THREADS>), dim3(g.max_units), dim3(WN9_THREADS), lds, st, WCN_ARGS);
     }
 #undef WCN_ARGS
 }

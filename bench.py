@@ -122,6 +122,22 @@ def extras(eng, torch, dev, steps, which="all"):
         torch.cuda.synchronize()
         return cnt, (time.perf_counter() - t0) / reps
 
+    # the drop-in as the reference calls it: host AoS in, one malloc'd result page out (PCIe inclusive, pageable memory)
+    n = 128_000_000 if which == "all" else 16_000_000
+    Rh, Sh = host_inputs(n, rhj.TUPLE)
+    eng.join(Rh[:1_000_000], Sh[:1_000_000])
+    secs = []
+    for _ in range(3):
+        cnt, dt_call = eng.join_count_only_page(Rh, Sh, timed=True)          # the C call alone (the page is freed outside)
+        secs.append(dt_call)
+    sec = sorted(secs)[1]
+    res[f"end_to_end_rhj_join_{n // 1_000_000}Mx{n // 1_000_000}M"] = {"ms": sec * 1e3, "tuples_per_s": 2 * n / sec, "matches": cnt,
+                                            "pcie_GBps": (32.0 * n + 16.0 * cnt) / sec / 1e9, "runs_ms": [round(x * 1e3, 1) for x in secs],
+                                            "s_chunks_pipelined": eng.info("last.pipelined"),
+                                            "note": "H2D of both inputs from pageable memory + kernels + D2H of the result page; pcie_GBps = (input + "
+                                                    "result bytes) / wall time, above one direction's wire rate when download overlaps upload"}
+    del Rh, Sh
+
     # config 2: 1M x 1M uniform, one 8-bit pass (what the automatic plan picks), device-resident
     n = 1_000_000
     R = torch.empty((n, 2), dtype=torch.int64, device=dev)
@@ -177,22 +193,6 @@ def extras(eng, torch, dev, steps, which="all"):
         del R, S, out
         eng.release_workspace()
         torch.cuda.empty_cache()
-
-    # the drop-in as the reference calls it: host AoS in, one malloc'd result page out (PCIe inclusive, pageable memory)
-    n = 128_000_000 if which == "all" else 16_000_000
-    Rh, Sh = host_inputs(n, rhj.TUPLE)
-    eng.join(Rh[:1_000_000], Sh[:1_000_000])
-    secs = []
-    for _ in range(3):
-        cnt, dt_call = eng.join_count_only_page(Rh, Sh, timed=True)          # the C call alone (the page is freed outside)
-        secs.append(dt_call)
-    sec = sorted(secs)[1]
-    res[f"end_to_end_rhj_join_{n // 1_000_000}Mx{n // 1_000_000}M"] = {"ms": sec * 1e3, "tuples_per_s": 2 * n / sec, "matches": cnt,
-                                            "pcie_GBps": (32.0 * n + 16.0 * cnt) / sec / 1e9, "runs_ms": [round(x * 1e3, 1) for x in secs],
-                                            "s_chunks_pipelined": eng.info("last.pipelined"),
-                                            "note": "H2D of both inputs from pageable memory + kernels + D2H of the result page; pcie_GBps = (input + "
-                                                    "result bytes) / wall time, above one direction's wire rate when download overlaps upload"}
-    del Rh, Sh
 
     # config 1's joins: the 94 multiRadixHashJoin calls the reference makes on small.work (sizes from the link-time tap,
     # tests/golden/small_joins.json), synthetic inputs of those sizes and match counts, through the host-pointer call

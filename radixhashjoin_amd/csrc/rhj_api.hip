@@ -1319,9 +1319,11 @@ int join_host_pipelined(rhj_ctx *ctx, const rhj_tuple *R, u64 nR, const rhj_tupl
     std::condition_variable cv;
     std::vector<std::pair<u64, u64>> todo;                 // (first pair, pairs)
     bool closing = false, dl_failed = false;
+    std::chrono::steady_clock::time_point t_faulted = t0, t_dl_first = t0;
     std::thread downloader([&] {
         (void)hipSetDevice(ctx->device);
         pre.wait();                                        // the helper threads still WRITE into the page while they fault it in
+        t_faulted = now();
         for (;;) {
             std::pair<u64, u64> job;
             {
@@ -1335,6 +1337,7 @@ int join_host_pipelined(rhj_ctx *ctx, const rhj_tuple *R, u64 nR, const rhj_tupl
                                           (size_t)job.second * 16, hipMemcpyDeviceToHost, ctx->down_stream);
             if (e == hipSuccess) e = hipStreamSynchronize(ctx->down_stream);
             if (e != hipSuccess) dl_failed = true;
+            if (t_dl_first == t0) t_dl_first = now();
         }
     });
     auto finish_downloader = [&] {
@@ -1415,8 +1418,10 @@ int join_host_pipelined(rhj_ctx *ctx, const rhj_tuple *R, u64 nR, const rhj_tupl
     ctx->last_pipelined = K;
     memset(page, 0, 8);                                    // bucket_info::next = nullptr (Result.h:14-17)
     if (trace)
-        fprintf(stderr, "[rhj_join pipelined %llu x %llu -> %llu, %d chunks of S] enqueued %.1f  tail (last join + download) %.1f  total %.1f ms\n",
-                (unsigned long long)nR, (unsigned long long)nS, (unsigned long long)count, K, ms(t0, t1), ms(t1, now()), ms(t0, now()));
+        fprintf(stderr, "[rhj_join pipelined %llu x %llu -> %llu, %d chunks of S] enqueued %.1f  tail (last join + download) %.1f  total %.1f ms"
+                        "  (result page faulted in at %.1f, first range home at %.1f)\n",
+                (unsigned long long)nR, (unsigned long long)nS, (unsigned long long)count, K, ms(t0, t1), ms(t1, now()), ms(t0, now()),
+                ms(t0, t_faulted), ms(t0, t_dl_first));
     *out_page = page;
     *out_count = count;
     return RHJ_OK;

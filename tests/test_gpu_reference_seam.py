@@ -26,16 +26,18 @@ def test_reference_code_drives_gpu_join(tmp_path, small_joins):
         pytest.skip(f"not built (needs the reference checkout at build time): {missing}")
     stdin = open(os.path.join(GOLD, "small", "small.init"), "rb").read() + open(os.path.join(GOLD, "small", "small.work"), "rb").read()
     expected = open(os.path.join(GOLD, "small", "small.result"), "rb").read()
-    procs = {}
+    # one binary after the other (a box has one GPU), each through communicate(): both pipes are drained while the child
+    # runs, so a child that writes more than a pipe buffer to stderr cannot block, and the timeout covers the whole exchange
     for b, p in paths.items():
         env = dict(os.environ, RHJ_SEAM_LOG=str(tmp_path / f"{b}.log"))
-        procs[b] = subprocess.Popen([p], stdin=subprocess.PIPE, stdout=subprocess.PIPE, stderr=subprocess.PIPE, cwd=GOLD, env=env)
-        procs[b].stdin.write(stdin)
-        procs[b].stdin.close()
-    for b, pr in procs.items():
-        out = pr.stdout.read()
-        err = pr.stderr.read()
-        assert pr.wait(timeout=900) == 0, (b, err[-2000:])
+        pr = subprocess.Popen([p], stdin=subprocess.PIPE, stdout=subprocess.PIPE, stderr=subprocess.PIPE, cwd=GOLD, env=env)
+        try:
+            out, err = pr.communicate(input=stdin, timeout=900)
+        except subprocess.TimeoutExpired:
+            pr.kill()
+            pr.communicate()
+            raise
+        assert pr.returncode == 0, (b, err[-2000:])
         assert out == expected, b                                 # 50 lines of SUMs / NULLs, byte-identical
     # the seam binary logs every call that went through rhj_join: the same 94 joins the CPU reference makes
     meta, _ = small_joins

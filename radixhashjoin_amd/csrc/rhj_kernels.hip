@@ -1787,10 +1787,14 @@ k_join_ct(const RelView<NARROW> R, const RelView<NARROW> S, const JoinTask *__re
             const bool longb = __ballot(maxlen > CT_MASK_BITS) != 0;         // a long bucket somewhere: the generic loop
             if (!longb) {
                 for (u32 j = 0; __ballot(j < maxlen) != 0; j++) {            // PT independent LDS reads per round
+                    // the PT reads first, then the PT compares: written as one loop the compiler issues read, wait, compare per
+                    // slot -- four LDS round trips per round behind one another (seen in the ISA: one destination register pair)
+                    u64 e[PT];
+#pragma unroll
+                    for (int s = 0; s < PT; s++) e[s] = ent[lo[s] + j];      // (past the bucket's end: some other entry, ignored)
 #pragma unroll
                     for (int s = 0; s < PT; s++) {
-                        const u64 e = ent[lo[s] + j];                        // (past the bucket's end: some other entry, ignored)
-                        const u32 xl = (u32)e ^ klo[s], xh = (u32)(e >> 32) ^ khi[s];
+                        const u32 xl = (u32)e[s] ^ klo[s], xh = (u32)(e[s] >> 32) ^ khi[s];
                         if (j < len[s] && xh == 0 && xl < 0x10000u) m[s] |= 0x10000u << j;
                     }
                 }

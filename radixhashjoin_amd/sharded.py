@@ -78,7 +78,7 @@ def _u64(x):
 
 class ShardedJoin:
     def __init__(self, engine, group=None, local_opts=None, owner_shift=OWNER_SHIFT_DEFAULT, fine_bits=None,
-                 balance=True, narrow=True, bind_stream=True, force_exchange=False):
+                 balance=True, narrow=True, bind_stream=True, force_exchange=False, rowid_mode=None):
         self.engine = engine
         self.group = group if group is not None else dist.group.WORLD
         self.world = dist.get_world_size(self.group)
@@ -95,6 +95,7 @@ class ShardedJoin:
         self.local_opts = local_opts
         self.narrow = narrow                 # False: always exchange 16-byte tuples
         self.bind_stream = bind_stream       # the engine launches on torch's current stream (no fences needed)
+        self.rowid_mode = rowid_mode         # tests: SHARD_TAGGED / SHARD_GLOBAL16 instead of what rhj_shard_plan suggests for the sizes
         self.force_exchange = force_exchange # world == 1: run the whole schedule anyway (collectives with oneself): the
         #                                      one-GPU box's way of executing the RCCL code path of a multi-GPU job
         self.collect_timings = False         # True: sum the engine's per-kernel HIP-event timings over the calls of a join
@@ -141,7 +142,9 @@ class ShardedJoin:
             from .binding import SHARD_PLAIN, shard_plan
             mode, plan = shard_plan(max(meta["recvR"]), max(meta["recvS"]), self.local_opts)
             # rowIDs that are all below 2^32 travel as they are (key_base 0 on every rank): the receiver has nothing to restore
-            if mode and all(_u64(head[r][3]) < (1 << 32) and _u64(head[r][5]) < (1 << 32) for r in range(self.world)):
+            if mode and self.rowid_mode:
+                mode = self.rowid_mode
+            elif mode and all(_u64(head[r][3]) < (1 << 32) and _u64(head[r][5]) < (1 << 32) for r in range(self.world)):
                 mode = SHARD_PLAIN
         if not mode:
             return self._join_tuple16(R, nR, S, nS, inR, outR, inS, outS, out)

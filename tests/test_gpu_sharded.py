@@ -18,7 +18,7 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def worker(rank, world, port, n_per_rank, D, zipf, opts, q):
+def worker(rank, world, port, n_per_rank, D, zipf, opts, q, shift=0, rowid_mode=None):
     sys.path.insert(0, ROOT)
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
@@ -36,16 +36,16 @@ def worker(rank, world, port, n_per_rank, D, zipf, opts, q):
     nglob = n_per_rank * world
     R = torch.empty((n_per_rank, 2), dtype=torch.int64, device=dev)
     S = torch.empty((n_per_rank, 2), dtype=torch.int64, device=dev)
-    eng.generate(GEN_R, R, n_per_rank, row0=rank * n_per_rank, D=D)
-    eng.generate(GEN_S_ZIPF if zipf else GEN_S_UNIFORM, S, n_per_rank, row0=rank * n_per_rank, D=D, seed=42, theta_milli=zipf or 0)
+    eng.generate(GEN_R, R, n_per_rank, row0=rank * n_per_rank + shift, D=D)                  # shift: rowIDs beyond 2^32
+    eng.generate(GEN_S_ZIPF if zipf else GEN_S_UNIFORM, S, n_per_rank, row0=rank * n_per_rank + shift, D=D, seed=42, theta_milli=zipf or 0)
     eng.sync()
-    sj = ShardedJoin(eng, dist.group.WORLD, local_opts=rhj.Opts(*opts) if opts else None)
+    sj = ShardedJoin(eng, dist.group.WORLD, local_opts=rhj.Opts(*opts) if opts else None, rowid_mode=rowid_mode)
     cnt, out = sj.join(R, n_per_rank, S, n_per_rank)
     torch.cuda.synchronize()
     pairs = out[:cnt].cpu().numpy().view(np.uint64)
     shards = [None] * world
     dist.all_gather_object(shards, (R.cpu().numpy().view(np.uint64), S.cpu().numpy().view(np.uint64), pairs,
-                                    sj.stats["recv_R"] + sj.stats["recv_S"], sj.stats["format"]))
+                                    sj.stats["recv_R"] + sj.stats["recv_S"], sj.stats["format"] + ":" + str(sj.stats.get("rowid_mode"))))
     if rank == 0:
         o = Oracle()
         def tup(parts):
@@ -54,7 +54,7 @@ def worker(rank, world, port, n_per_rank, D, zipf, opts, q):
             t["key"], t["payload"] = a[:, 0], a[:, 1]
             return t
         Rg, Sg = tup([s[0] for s in shards]), tup([s[1] for s in shards])
-        assert np.array_equal(Rg["key"], np.arange(nglob, dtype=np.uint64))            # rowIDs stay global
+        assert np.array_equal(Rg["key"], np.arange(nglob, dtype=np.uint64) + np.uint64(shift))    # rowIDs stay global
         exp = o.join(Rg, Sg)
         allp = np.concatenate([s[2] for s in shards])
         a = allp[np.lexsort((allp[:, 1], allp[:, 0]))]
@@ -75,17 +75,19 @@ def free_port():
     return p
 
 
-@pytest.mark.parametrize("world,n_per_rank,D,zipf,opts,fmt", [
-    (2, 1_500_000, 3_000_000, 0, None, "tuple16"),           # PK/FK, automatic local plan (one pass: 16-byte fallback)
-    (2, 400_000, 100_000, 0, (2, 4, 4), "narrow12"),         # duplicates, forced two-pass plan: 12-byte wire format
-    (3, 300_000, 900_000, 1250, None, "tuple16"),            # skew, 3 ranks
-    (3, 500_000, 1_500_000, 1250, (2, 6, 6), "narrow12"),    # skew, 3 ranks, narrow
-    (2, 3_000_000, 6_000_000, 0, (2, 8, 8), "narrow12")])    # the 8+8 plan of the large configurations
-def test_sharded_join_real_engine(world, n_per_rank, D, zipf, opts, fmt):
+@pytest.mark.parametrize("world,n_per_rank,D,zipf,opts,fmt,shift,mode", [
+    (2, 1_500_000, 3_000_000, 0, None, "tuple16:None", 0, None),           # PK/FK, automatic local plan (one pass: 16-byte fallback)
+    (2, 400_000, 100_000, 0, (2, 4, 4), "narrow12:plain", 0, None),        # duplicates, forced two-pass plan: 12-byte wire format
+    (3, 300_000, 900_000, 1250, None, "tuple16:None", 0, None),            # skew, 3 ranks
+    (3, 500_000, 1_500_000, 1250, (2, 6, 6), "narrow12:plain", 0, None),   # skew, 3 ranks, narrow
+    (2, 3_000_000, 6_000_000, 0, (2, 8, 8), "narrow12:plain", 0, None),    # the 8+8 plan of the large configurations
+    (3, 400_000, 300_000, 0, (2, 5, 5), "narrow12:tagged", 1 << 33, None),   # rowIDs beyond 2^32: sender tags
+    (2, 500_000, 1_000_000, 0, (2, 8, 8), "narrow12:global16", 1 << 34, 2)])  # ... or 16-byte final partitions (what 8 x 10^9 rows use)
+def test_sharded_join_real_engine(world, n_per_rank, D, zipf, opts, fmt, shift, mode):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = free_port()
-    procs = [ctx.Process(target=worker, args=(r, world, port, n_per_rank, D, zipf, opts, q)) for r in range(world)]
+    procs = [ctx.Process(target=worker, args=(r, world, port, n_per_rank, D, zipf, opts, q, shift, mode)) for r in range(world)]
     for p in procs:
         p.start()
     got, exp, same, imbalance, used = q.get(timeout=600)

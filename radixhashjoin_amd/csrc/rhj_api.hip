@@ -1271,7 +1271,7 @@ int join_host_pipelined(rhj_ctx *ctx, const rhj_tuple *R, u64 nR, const rhj_tupl
     static const bool off = getenv("RHJ_NO_PIPELINE") != nullptr;                 // tuning aid: A/B against the plain path
     static const bool trace = getenv("RHJ_TRACE_JOIN") != nullptr;
     int K = (int)(nS / PIPE_MIN_CHUNK < (u64)PIPE_MAX_CHUNKS ? nS / PIPE_MIN_CHUNK : (u64)PIPE_MAX_CHUNKS);
-    if (off || plan.passes != 2 || K < 2 || nR < PIPE_MIN_CHUNK / 4) return RHJ_NOT_PIPELINED;
+    if (off || plan.passes < 1 || K < 2 || nR < PIPE_MIN_CHUNK / 4) return RHJ_NOT_PIPELINED;
     const u64 chunk = ((nS + K - 1) / K + 4095) / 4096 * 4096;
     K = (int)((nS + chunk - 1) / chunk);
     auto now = [] { return std::chrono::steady_clock::now(); };
@@ -1284,7 +1284,7 @@ int join_host_pipelined(rhj_ctx *ctx, const rhj_tuple *R, u64 nR, const rhj_tupl
     pre.start((size_t)cap);
     if (!pre.page) return RHJ_NOT_PIPELINED;
     const int narrow = narrow_level(ctx, nR, chunk, plan);
-    const int tb = plan.bits1 + plan.bits2;
+    const int tb = plan.bits1 + (plan.passes == 2 ? plan.bits2 : 0);
     const size_t np = (size_t)1 << tb;
     auto setup = [&]() -> int {
         RHJCHK(ensure(ctx, ctx->in_R, (size_t)nR * 16));

@@ -49,3 +49,27 @@ def test_pipelined_host_join_equals_the_closed_form(n):
         assert checksum(got2) == exp_c
     finally:
         e.close()
+
+
+def test_pipelined_with_a_one_pass_plan_and_a_small_build_side():
+    """|R| = 6M (one 9-bit pass), |S| = 40M: S still goes through in chunks"""
+    n, m = 6_000_000, 40_000_000
+    i = np.arange(n, dtype=np.uint64)
+    R = np.empty(n, dtype=TUPLE)
+    R["key"], R["payload"] = i, bench.np_mix(i + np.uint64(1))
+    j = np.arange(m, dtype=np.uint64)
+    S = np.empty(m, dtype=TUPLE)
+    S["key"] = j
+    k1 = bench.np_mix(j ^ np.uint64(42)) % np.uint64(n)
+    S["payload"] = bench.np_mix(k1 + np.uint64(1))
+    S["payload"][::11] ^= np.uint64(1 << 50)                 # every 11th foreign key matches nothing
+    hit = np.ones(m, dtype=bool)
+    hit[::11] = False
+    exp_c = int(np.sum(bench.np_mix(k1[hit] * C ^ bench.np_mix(j[hit])), dtype=np.uint64))
+    e = Engine(0)
+    try:
+        got = e.join(R, S)
+        assert e.info("last.pipelined") == 2
+        assert len(got) == int(hit.sum()) and checksum(got) == exp_c
+    finally:
+        e.close()

@@ -105,6 +105,108 @@ def cpu_baseline(sample_n, reps=5):
     return out
 
 
+def shard_rank_kernel_time(eng, torch, dev, world, n, dist_kind):
+    """BASELINE config 5 as far as ONE GPU can measure it: this process plays rank 0 of `world` ranks of the sharded join
+    (radixhashjoin_amd/sharded.py; n rows of R and of S per rank, rowIDs global): every rank's shards are generated, their
+    class histograms gathered, the class ranges cut, every rank's shard split into the 12-byte wire format -- and rank 0
+    receives what the all-to-all would deliver (device-side copies of the other ranks' slices), partitions it and joins it.
+    Returns the device time of rank 0's kernels (HIP events of the engine, the figure `kernel_ms_per_step` reports for the
+    single-GPU step) next to the bytes that would cross xGMI.  Verified: rank 0's pairs against the closed form."""
+    import numpy as np
+    from radixhashjoin_amd.binding import (GEN_R, GEN_S_UNIFORM, GEN_S_ZIPF, SHARD_PLAIN, narrow_bytes, narrow_key_offset, shard_plan)
+    from radixhashjoin_amd.sharded import balanced_cuts
+    SHIFT, BITS = 20, 8
+    nglob = n * world
+    kind = GEN_S_ZIPF if dist_kind == "zipf" else GEN_S_UNIFORM
+    acc = {"stats": 0.0, "split": 0.0, "partition": 0.0, "join": 0.0}
+
+    def collect(tag):
+        t = eng.timings()
+        acc[tag] += sum(v["ms"] for v in t.values() if isinstance(v, dict))
+
+    def shards(rank):
+        R = torch.empty((n, 2), dtype=torch.int64, device=dev)
+        S = torch.empty((n, 2), dtype=torch.int64, device=dev)
+        eng.generate(GEN_R, R, n, row0=rank * n, D=nglob)
+        eng.generate(kind, S, n, row0=rank * n, D=nglob, seed=42, theta_milli=900)
+        return R, S
+
+    eng.set_profiling(True)
+    hists, kmins, kmaxs = [], [], []
+    for rank in range(world):                                   # the all-gather: every rank's class counts and rowID ranges
+        R, S = shards(rank)
+        for side, rel in ((0, R), (1, S)):
+            h, lo, hi = eng.shard_stats(side, rel, n, SHIFT, BITS)
+            hists.append(h); kmins.append(lo); kmaxs.append(hi)
+        del R, S
+    cuts = balanced_cuts(np.sum(hists, axis=0).tolist(), world)
+    lo_c, hi_c = cuts[0], cuts[1]
+    recv = [sum(int(hists[2 * r + side][cuts[d]:cuts[d + 1]].sum()) for r in range(world)) for side in (0, 1) for d in range(world)]
+    mode, plan = shard_plan(max(recv[:world]), max(recv[world:]), None)
+    if not mode:
+        return {"skipped": "sizes outside the narrow sharded path"}
+    plain = max(kmaxs) < (1 << 32)
+    if plain:
+        mode = SHARD_PLAIN
+    row0 = {side: [0 if plain else kmins[2 * r + side] for r in range(world)] for side in (0, 1)}
+    pieces = {0: [], 1: []}
+    sent_bytes = 0
+    exp_cnt = exp_chk = 0
+    for rank in range(world):                                   # every rank splits; rank 0 keeps what it would receive
+        R, S = shards(rank)
+        for side, rel in ((0, R), (1, S)):
+            buf = torch.empty(max(narrow_bytes(n), 16), dtype=torch.uint8, device=dev)
+            eng.shard_stats(side, rel, n, SHIFT, BITS)          # (the unit tables the split uses; what the rank itself runs first)
+            if rank == 0:
+                collect("stats")
+            eng.shard_split(side, rel, n, SHIFT, BITS, row0[side][rank], buf)
+            if rank == 0:
+                collect("split")
+            st = np.concatenate([[0], np.cumsum(hists[2 * rank + side])])
+            x, y = int(st[lo_c]), int(st[hi_c])
+            koff = narrow_key_offset(n)
+            pieces[side].append((buf[8 * x:8 * y].view(torch.int64).clone(), buf[koff + 4 * x:koff + 4 * y].view(torch.int32).clone()))
+            if rank == 0:
+                sent_bytes += 12 * (n - (y - x))
+            del buf
+        del R, S
+    seg = {side: [0] for side in (0, 1)}
+    arr = {}
+    for side in (0, 1):
+        for P, K in pieces[side]:
+            seg[side].append(seg[side][-1] + P.shape[0])
+        arr[side] = (torch.cat([p for p, _ in pieces[side]]), torch.cat([k for _, k in pieces[side]]))
+    del pieces
+    mR, mS = seg[0][-1], seg[1][-1]
+    for side in (0, 1):
+        eng.shard_partition(side, arr[side][0], arr[side][1], seg[side][-1], seg[side], row0[side], plan, mode)
+        collect("partition")
+    out = torch.empty((max(mR, mS) + 1024, 2), dtype=torch.int64, device=dev)
+    cnt = eng.shard_join(out, out.shape[0])
+    collect("join")
+    eng.set_profiling(False)
+    # rank 0 owns classes [lo_c, hi_c): its pairs are exactly the S tuples of those classes (PK/FK, every S tuple matches once)
+    chk = eng.pairs_checksum(out, cnt)
+    # closed form over what rank 0 received of S: payload = mix(k) matches R row k - 1; rowID = row0 + local
+    Sx = torch.empty((mS, 2), dtype=torch.int64, device=dev)
+    base = torch.zeros(mS, dtype=torch.int64, device=dev)
+    for r in range(world):
+        base[seg[1][r]:seg[1][r + 1]] = row0[1][r] if row0[1][r] < (1 << 63) else row0[1][r] - (1 << 64)
+    Sx[:, 0] = arr[1][1].to(torch.int64) & 0xFFFFFFFF
+    Sx[:, 0] += base
+    Sx[:, 1] = arr[1][0]
+    exp_cnt, exp_chk = eng.expected_pkfk(Sx, mS)
+    total = sum(acc.values())
+    return {"world_emulated": world, "rows_per_rank": n, "dist": dist_kind, "rowid_mode": {1: "tagged", 2: "global16", 3: "plain"}[mode],
+            "local_plan": [plan.passes, plan.bits1, plan.bits2], "recv_tuples_rank0": [mR, mS],
+            "rank0_kernel_ms": {k: round(v, 3) for k, v in acc.items()}, "rank0_kernel_ms_total": round(total, 3),
+            "exchange_bytes_per_rank": sent_bytes, "bytes_per_tuple_sent": 12,
+            "xgmi_ms_at_153GBps_per_link": round(sent_bytes / max(world - 1, 1) / 153e9 * 1e3, 2),
+            "verified": (cnt, chk) == (exp_cnt, exp_chk),
+            "note": "one GPU playing rank 0 of the sharded join with real segments from every emulated rank; device time of its "
+                    "kernels; the exchange itself is modelled (direct peer links, all busy)"}
+
+
 def extras(eng, torch, dev, steps, which="all"):
     """N == 1 only, outside the timed region: the other BASELINE configs and the host-pointer drop-in, so that every
     number DESIGN.md quotes is on the driver's record.  Each leg verifies its pair set (count + checksum)."""
@@ -169,6 +271,14 @@ def extras(eng, torch, dev, steps, which="all"):
         del R, S, out
     eng.release_workspace()
     torch.cuda.empty_cache()
+
+    # BASELINE config 5, per rank: what one GPU of an 8-GPU job computes at 10^9 rows per rank (uniform), and of a 4-GPU job
+    free, _ = eng.mem_info()
+    if which == "all" and free > 200e9:
+        for world_ in (8, 4):
+            res[f"c5_sharded_rank0_of_{world_}_1Bx1B_per_rank"] = shard_rank_kernel_time(eng, torch, dev, world_, 1_000_000_000, "uniform")
+            eng.release_workspace()
+            torch.cuda.empty_cache()
 
     # beyond the 16-bit plans (the engine's own scaling axis; the reference has one fixed 8-bit pass, Result.cpp:5,91):
     # 1.5 and 2.2 * 10^9 tuples per side under the automatic plan (17 bits = 9+8, narrow format), HBM permitting

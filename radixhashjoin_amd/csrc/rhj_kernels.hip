@@ -14,6 +14,15 @@
 // k_join_ct              the same for partitions of up to 17920 build tuples under plans that remove >= 16 payload
 //                        bits: 8 B entries, both sides read once                           HBM + LDS latency
 // k_*2                   the one-pass kernels with grid.y = relation: R and S of a join through the same launches
+// k_scatter_wcn          the same scatter writing the narrow {payload 8 B, rowID 4 B} format inside a join: 32-tuple carry lines for
+//                        <= 8-bit passes, 16-tuple lines for 9-bit passes (17-18-bit plans)                HBM read+write (28 / 24 B/tuple)
+// k_hist_units_n         HistogramJob::run over a narrow payload array (pass 2 of 17-18-bit plans)          HBM read (8 B/tuple)
+// multi-GPU receiver / sender (no reference counterpart: the reference is one process):
+// k_seg_units            pass-1 units cut at the sender segments of a received shard
+// k_hist2d_units<true>   the two-pass histogram over received payloads                                       HBM read (8 B/tuple)
+// k_scatter_wc_n         last pass in front of the compact-table join: narrow in, 16-byte tuples with global rowIDs out
+// k_join_bkt<..TAGGED>   the one-table join resolving {sender tag, shard-local rowID} into global rowIDs
+// k_check_radix          contract check of the public rhj_bucket_join (radix_bits must describe the partitions)
 //
 // No MFMA anywhere: the path is 64-bit integer hashing and data movement, bounded by HBM.
 #include "rhj_internal.h"

@@ -1262,16 +1262,17 @@ namespace {
 // ranges of pairs home into the result page.  Returns RHJ_NOT_PIPELINED when the call should take the plain path instead
 // (small inputs, a rowID that does not fit the narrow format, more pairs than the optimistic page holds).
 constexpr int RHJ_NOT_PIPELINED = 1001;
-constexpr u64 PIPE_MIN_CHUNK = (u64)16 << 20;          // tuples per S chunk at least
-constexpr int PIPE_MAX_CHUNKS = 8;
+constexpr u64 PIPE_MIN_CHUNK = (u64)8 << 20;           // tuples per S chunk at least
+constexpr int PIPE_MAX_CHUNKS = 16;
 
 int join_host_pipelined(rhj_ctx *ctx, const rhj_tuple *R, u64 nR, const rhj_tuple *S, u64 nS, const rhj_opts &plan,
                         void **out_page, u64 *out_count)
 {
     static const bool off = getenv("RHJ_NO_PIPELINE") != nullptr;                 // tuning aid: A/B against the plain path
     static const bool trace = getenv("RHJ_TRACE_JOIN") != nullptr;
-    int K = (int)(nS / PIPE_MIN_CHUNK < (u64)PIPE_MAX_CHUNKS ? nS / PIPE_MIN_CHUNK : (u64)PIPE_MAX_CHUNKS);
-    if (off || plan.passes < 1 || K < 2 || nR < PIPE_MIN_CHUNK / 4) return RHJ_NOT_PIPELINED;
+    static const u64 max_chunks = env_u64("RHJ_PIPE_CHUNKS", 12, 2, PIPE_MAX_CHUNKS);   // tuning aid
+    int K = (int)(nS / PIPE_MIN_CHUNK < max_chunks ? nS / PIPE_MIN_CHUNK : max_chunks);
+    if (off || plan.passes < 1 || nS < 4 * PIPE_MIN_CHUNK || K < 2 || nR < PIPE_MIN_CHUNK / 2) return RHJ_NOT_PIPELINED;
     const u64 chunk = ((nS + K - 1) / K + 4095) / 4096 * 4096;
     K = (int)((nS + chunk - 1) / chunk);
     auto now = [] { return std::chrono::steady_clock::now(); };

@@ -17,6 +17,13 @@ pytestmark = pytest.mark.gpu
 C = np.uint64(0x100000001B3)
 
 
+def chunks_of(nS):
+    """the S chunks rhj_join uses (rhj_api.hip, join_host_pipelined): >= 8 Mi tuples each, at most 12"""
+    k0 = min(12, nS // (8 << 20))
+    chunk = (-(-nS // k0) + 4095) // 4096 * 4096
+    return -(-nS // chunk)
+
+
 def checksum(pairs):
     return int(np.sum(bench.np_mix(pairs["keyR"] * C ^ bench.np_mix(pairs["keyS"])), dtype=np.uint64))
 
@@ -37,7 +44,7 @@ def test_pipelined_host_join_equals_the_closed_form(n):
         got = e.join(R, S)
         exp_n, exp_c = expected(S, n)
         assert len(got) == exp_n and checksum(got) == exp_c
-        assert e.info("last.narrow") == 2 and e.info("last.pipelined") == min(8, len(S) // (16 << 20))
+        assert e.info("last.narrow") == 2 and e.info("last.pipelined") == chunks_of(len(S))
         # a rowID beyond 2^32 on the build side: the pipelined attempt is abandoned, the plain path repeats the join in the
         # 16-byte format; same pairs but for that one rowID
         R2 = R.copy()
@@ -69,7 +76,7 @@ def test_pipelined_with_a_one_pass_plan_and_a_small_build_side():
     e = Engine(0)
     try:
         got = e.join(R, S)
-        assert e.info("last.pipelined") == 2
+        assert e.info("last.pipelined") == chunks_of(m)
         assert len(got) == int(hit.sum()) and checksum(got) == exp_c
     finally:
         e.close()

@@ -1635,6 +1635,11 @@ constexpr int CTH_THREADS = 512, CTH_CHUNK = 8960, CTH_BUCKET_BITS = 12;
 // just beyond one 16-slot task (2.2 * 10^9 tuples under 17 or 18 bits: 16.8 K / 8.4 K per partition) would otherwise be cut into
 // two tasks that both build the whole table
 constexpr int CT_EPT_WIDE = 20;
+// ... and a middle geometry: 12288 entries, 12 build and 12 probe slots per thread (1024 threads, one workgroup per CU).  The
+// kernel's cost per task follows its slot rows, not the partition: partitions of 8.4 - 11.5 K tuples (5.5 - 7.5 * 10^8 tuples under
+// 16 bits, 1.1 - 1.5 * 10^9 under 17) paid for 18 + 16 rows in the full-size geometry ([measured] join kernel 8.5 -> 6.6 ms at
+// 6 * 10^8, 17.6 -> 14.1 at 1.5 * 10^9; 16 + 16 rows for the 15.3 K-tuple partitions of 10^9 tuples: 10.09 -> 10.02, not kept).
+constexpr int CTM_CHUNK = 12288, CTM_EPT = 12;
 constexpr u32 CT_NONE = 0xFFFFu;
 constexpr int CT_MIN_RADIX_BITS = 16;       // keys must fit 48 bits
 constexpr u32 CT_MASK_BITS = 16;            // a probe records its matches as a bit mask over a bucket of at most this many entries
@@ -2070,12 +2075,13 @@ constexpr int BJ2_THREADS = 1024, BJ2_CHUNK = 8448, BJ2_BUCKET_BITS = 12, BJ2_EP
 u32 join_probe_split(int kind)
 {
     return kind == JK_CT ? (u32)(CT_THREADS * CT_EPT) : kind == JK_CT_HALF ? (u32)(CTH_THREADS * CT_EPT) :
-           kind == JK_CT_WIDE ? (u32)(CT_THREADS * CT_EPT_WIDE) : kind == JK_CT_HALF_WIDE ? (u32)(CTH_THREADS * CT_EPT_WIDE) : 0u;
+           kind == JK_CT_WIDE ? (u32)(CT_THREADS * CT_EPT_WIDE) : kind == JK_CT_HALF_WIDE ? (u32)(CTH_THREADS * CT_EPT_WIDE) :
+           kind == JK_CT_MID ? (u32)(CT_THREADS * CTM_EPT) : 0u;
 }
 u32 join_table_tuples(int kind)
 {
     return kind == JK_CT || kind == JK_CT_WIDE ? (u32)CT_CHUNK : kind == JK_CT_HALF || kind == JK_CT_HALF_WIDE ? (u32)CTH_CHUNK :
-           kind == JK_BKT_BIG ? (u32)BJ2_CHUNK : (u32)BJ_CHUNK;
+           kind == JK_CT_MID ? (u32)CTM_CHUNK : kind == JK_BKT_BIG ? (u32)BJ2_CHUNK : (u32)BJ_CHUNK;
 }
 int join_ct_min_radix_bits() { return CT_MIN_RADIX_BITS; }
 
@@ -2140,6 +2146,8 @@ static void allow_big_lds()
     SET_LDS((k_join_ct<CT_THREADS, CT_CHUNK, CT_BUCKET_BITS, CT_EPT, false, true>), ct_lds_bytes());
     SET_LDS((k_join_ct<CTH_THREADS, CTH_CHUNK, CTH_BUCKET_BITS, CT_EPT, false, true>), ct_lds_bytes(CTH_THREADS, CTH_CHUNK, CTH_BUCKET_BITS));
     SET_LDS((k_join_ct<CT_THREADS, CT_CHUNK, CT_BUCKET_BITS, CT_EPT_WIDE, false, true>), ct_lds_bytes());
+    SET_LDS((k_join_ct<CT_THREADS, CTM_CHUNK, CT_BUCKET_BITS, CTM_EPT, false, true>), ct_lds_bytes(CT_THREADS, CTM_CHUNK, CT_BUCKET_BITS));
+    SET_LDS((k_join_ct<CT_THREADS, CTM_CHUNK, CT_BUCKET_BITS, CTM_EPT, false, false>), ct_lds_bytes(CT_THREADS, CTM_CHUNK, CT_BUCKET_BITS));
     SET_LDS((k_join_ct<CTH_THREADS, CTH_CHUNK, CTH_BUCKET_BITS, CT_EPT_WIDE, false, true>), ct_lds_bytes(CTH_THREADS, CTH_CHUNK, CTH_BUCKET_BITS));
     SET_LDS((k_join_bkt<BJ_THREADS, BJ_CHUNK, BJ_BUCKET_BITS, BJ_EPT, false, true, true>), bj_lds_bytes(BJ_THREADS, BJ_CHUNK, BJ_BUCKET_BITS));
     SET_LDS(k_scatter_wc_n<WC_THREADS>, wc_lds_bytes(WC_MAX_BITS, WC_THREADS));
@@ -2446,6 +2454,7 @@ void launch_join(hipStream_t st, const void *d_R, const u64 *d_startR, const voi
         else if (kind == JK_CT_HALF) LAUNCH_CT_N(CTH_THREADS, CTH_CHUNK, CTH_BUCKET_BITS, CT_EPT);
         else if (kind == JK_CT_HALF_WIDE) LAUNCH_CT_N(CTH_THREADS, CTH_CHUNK, CTH_BUCKET_BITS, CT_EPT_WIDE);
         else if (kind == JK_CT_WIDE) LAUNCH_CT_N(CT_THREADS, CT_CHUNK, CT_BUCKET_BITS, CT_EPT_WIDE);
+        else if (kind == JK_CT_MID) LAUNCH_CT_N(CT_THREADS, CTM_CHUNK, CT_BUCKET_BITS, CTM_EPT);
         else LAUNCH_CT_N(CT_THREADS, CT_CHUNK, CT_BUCKET_BITS, CT_EPT);     // JK_CT (the host never asks for another kind here)
 #undef LAUNCH_BKT_N
 #undef LAUNCH_CT_N
@@ -2461,6 +2470,12 @@ void launch_join(hipStream_t st, const void *d_R, const u64 *d_startR, const voi
         hipLaunchKernelGGL((k_join_bkt<BJ2_THREADS, BJ2_CHUNK, BJ2_BUCKET_BITS, BJ2_EPT, false>), dim3(grid), dim3(BJ2_THREADS),
                            bj_lds_bytes(BJ2_THREADS, BJ2_CHUNK, BJ2_BUCKET_BITS), st, vR, vS,
                            d_tasks, d_ntasks, radix_bits, (Pair *)d_out, out_capacity, d_out_count, DirectJoin{});
+        return;
+    }
+    if (kind == JK_CT_MID) {
+        hipLaunchKernelGGL((k_join_ct<CT_THREADS, CTM_CHUNK, CT_BUCKET_BITS, CTM_EPT, false, false>), dim3(grid), dim3(CT_THREADS),
+                           ct_lds_bytes(CT_THREADS, CTM_CHUNK, CT_BUCKET_BITS), st, vR, vS, d_tasks,
+                           d_ntasks, radix_bits, (Pair *)d_out, out_capacity, d_out_count, (u64 *)nullptr, 0u, (const u32 *)nullptr);
         return;
     }
     if (kind == JK_CT_HALF) {

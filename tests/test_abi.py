@@ -55,7 +55,8 @@ def test_plan_auto():
     p = P(10**9, 10**9, O(2, 8, 8))
     assert (p.passes, p.bits1, p.bits2) == (2, 8, 8)    # BASELINE config 3 as named
     p = P(2 * 10**9, 2 * 10**9)
-    assert (p.passes, p.bits1, p.bits2) == (2, 9, 8)    # a 16-bit partition would not fit one compact table any more: 17 bits
+    assert (p.passes, p.bits1, p.bits2) == (2, 8, 9)    # a 16-bit partition would not fit one compact table any more: 17 bits,
+                                                        # the 9-bit pass second (from the narrow intermediate)
     p = P(2_300_000_000, 3 * 10**9)
     assert (p.passes, p.bits1, p.bits2) == (2, 9, 9)    # ... 18 beyond 2.2 * 10^9 (both in the narrow format)
     p = P(8 * 10**9, 8 * 10**9)

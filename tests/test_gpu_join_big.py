@@ -91,7 +91,7 @@ def test_generated_inputs_forced_big(big, oracle, plan):
     check(big, oracle, R, S, plan)
 
 
-@pytest.mark.parametrize("plan", [Opts(2, 9, 8), Opts(2, 9, 9)])
+@pytest.mark.parametrize("plan", [Opts(2, 8, 9), Opts(2, 9, 8), Opts(2, 9, 9)])
 def test_17_and_18_bit_plans_narrow(big, oracle, plan):
     """plans beyond 16 bits (what 1.1 - 4.4 * 10^9 tuples per side get): two narrow passes with separate histograms, the 9-bit
     ones with 16-tuple carry lines; large partitions (few low-bit patterns), duplicates, unmatched probes, and the fall-back
@@ -236,7 +236,7 @@ def test_beyond_the_16_bit_plans_count_and_checksum(engine, n, kind):
     if free < 16 * n * 6.2:
         pytest.skip("not enough free HBM")
     p = resolve(n, n)
-    assert (p.passes, p.bits1, p.bits2) == (2, 9, 8)                          # 17 bits up to 2.2 * 10^9, 18 beyond
+    assert (p.passes, p.bits1, p.bits2) == (2, 8, 9)                          # 17 bits up to 2.2 * 10^9, 18 beyond
     dR, dS, dO = engine.alloc(16 * n), engine.alloc(16 * n), engine.alloc(16 * n)
     engine.generate(GEN_R, dR, n, 0, n)
     engine.generate(kind, dS, n, 0, n, seed=42, theta_milli=900)

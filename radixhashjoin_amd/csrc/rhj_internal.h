@@ -94,8 +94,9 @@ bool fused_two_pass_ok(int b1, int b2);
 // bucket-join kernels: JK_BKT partitions that fit one 4224-tuple table (two workgroups per CU); JK_BKT_BIG 8448-tuple
 // chunks, probe side re-read per chunk (any radix plan); JK_CT compact 8-byte entries, both sides read once
 // (plans that remove >= 16 payload bits)
-enum JoinKernel { JK_BKT = 0, JK_BKT_BIG = 1, JK_CT = 2, JK_CT_HALF = 3, JK_CT_WIDE = 4, JK_CT_HALF_WIDE = 5, JK_CT_MID = 6 };
-// _WIDE: 20 probe slots per thread (narrow format only); _MID: a 12288-entry table and 12 slots per thread (partitions of 8.4 - 11.5 K)
+enum JoinKernel { JK_BKT = 0, JK_BKT_BIG = 1, JK_CT = 2, JK_CT_HALF = 3, JK_CT_WIDE = 4, JK_CT_HALF_WIDE = 5, JK_CT_MID = 6, JK_CT_HALF_MID = 7 };
+// _WIDE: 20 probe slots per thread (narrow format only); _MID: a 12288-entry table and 12 slots per thread (partitions of 8.4 - 11.5 K);
+// _HALF_MID: the same at half size, 6144 entries, 512 threads, two workgroups per CU (partitions of 4.2 - 5.8 K)
 u32 join_probe_split(int kind);      // probe tuples per task the kernel holds at most (0: no limit of its own)
 u32 join_table_tuples(int kind);     // build tuples per LDS table
 int join_ct_min_radix_bits();

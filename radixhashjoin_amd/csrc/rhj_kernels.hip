@@ -1640,6 +1640,7 @@ constexpr int CT_EPT_WIDE = 20;
 // 16 bits, 1.1 - 1.5 * 10^9 under 17) paid for 18 + 16 rows in the full-size geometry ([measured] join kernel 8.5 -> 6.6 ms at
 // 6 * 10^8, 17.6 -> 14.1 at 1.5 * 10^9; 16 + 16 rows for the 15.3 K-tuple partitions of 10^9 tuples: 10.09 -> 10.02, not kept).
 constexpr int CTM_CHUNK = 12288, CTM_EPT = 12;
+constexpr int CTHM_CHUNK = 6144;                    // ... and at half size (512 threads, two workgroups per CU): 4.2 - 5.8 K-tuple partitions
 constexpr u32 CT_NONE = 0xFFFFu;
 constexpr int CT_MIN_RADIX_BITS = 16;       // keys must fit 48 bits
 constexpr u32 CT_MASK_BITS = 16;            // a probe records its matches as a bit mask over a bucket of at most this many entries
@@ -2076,12 +2077,12 @@ u32 join_probe_split(int kind)
 {
     return kind == JK_CT ? (u32)(CT_THREADS * CT_EPT) : kind == JK_CT_HALF ? (u32)(CTH_THREADS * CT_EPT) :
            kind == JK_CT_WIDE ? (u32)(CT_THREADS * CT_EPT_WIDE) : kind == JK_CT_HALF_WIDE ? (u32)(CTH_THREADS * CT_EPT_WIDE) :
-           kind == JK_CT_MID ? (u32)(CT_THREADS * CTM_EPT) : 0u;
+           kind == JK_CT_MID ? (u32)(CT_THREADS * CTM_EPT) : kind == JK_CT_HALF_MID ? (u32)(CTH_THREADS * CTM_EPT) : 0u;
 }
 u32 join_table_tuples(int kind)
 {
     return kind == JK_CT || kind == JK_CT_WIDE ? (u32)CT_CHUNK : kind == JK_CT_HALF || kind == JK_CT_HALF_WIDE ? (u32)CTH_CHUNK :
-           kind == JK_CT_MID ? (u32)CTM_CHUNK : kind == JK_BKT_BIG ? (u32)BJ2_CHUNK : (u32)BJ_CHUNK;
+           kind == JK_CT_MID ? (u32)CTM_CHUNK : kind == JK_CT_HALF_MID ? (u32)CTHM_CHUNK : kind == JK_BKT_BIG ? (u32)BJ2_CHUNK : (u32)BJ_CHUNK;
 }
 int join_ct_min_radix_bits() { return CT_MIN_RADIX_BITS; }
 
@@ -2148,6 +2149,8 @@ static void allow_big_lds()
     SET_LDS((k_join_ct<CT_THREADS, CT_CHUNK, CT_BUCKET_BITS, CT_EPT_WIDE, false, true>), ct_lds_bytes());
     SET_LDS((k_join_ct<CT_THREADS, CTM_CHUNK, CT_BUCKET_BITS, CTM_EPT, false, true>), ct_lds_bytes(CT_THREADS, CTM_CHUNK, CT_BUCKET_BITS));
     SET_LDS((k_join_ct<CT_THREADS, CTM_CHUNK, CT_BUCKET_BITS, CTM_EPT, false, false>), ct_lds_bytes(CT_THREADS, CTM_CHUNK, CT_BUCKET_BITS));
+    SET_LDS((k_join_ct<CTH_THREADS, CTHM_CHUNK, CTH_BUCKET_BITS, CTM_EPT, false, true>), ct_lds_bytes(CTH_THREADS, CTHM_CHUNK, CTH_BUCKET_BITS));
+    SET_LDS((k_join_ct<CTH_THREADS, CTHM_CHUNK, CTH_BUCKET_BITS, CTM_EPT, false, false>), ct_lds_bytes(CTH_THREADS, CTHM_CHUNK, CTH_BUCKET_BITS));
     SET_LDS((k_join_ct<CTH_THREADS, CTH_CHUNK, CTH_BUCKET_BITS, CT_EPT_WIDE, false, true>), ct_lds_bytes(CTH_THREADS, CTH_CHUNK, CTH_BUCKET_BITS));
     SET_LDS((k_join_bkt<BJ_THREADS, BJ_CHUNK, BJ_BUCKET_BITS, BJ_EPT, false, true, true>), bj_lds_bytes(BJ_THREADS, BJ_CHUNK, BJ_BUCKET_BITS));
     SET_LDS(k_scatter_wc_n<WC_THREADS>, wc_lds_bytes(WC_MAX_BITS, WC_THREADS));
@@ -2455,6 +2458,7 @@ void launch_join(hipStream_t st, const void *d_R, const u64 *d_startR, const voi
         else if (kind == JK_CT_HALF_WIDE) LAUNCH_CT_N(CTH_THREADS, CTH_CHUNK, CTH_BUCKET_BITS, CT_EPT_WIDE);
         else if (kind == JK_CT_WIDE) LAUNCH_CT_N(CT_THREADS, CT_CHUNK, CT_BUCKET_BITS, CT_EPT_WIDE);
         else if (kind == JK_CT_MID) LAUNCH_CT_N(CT_THREADS, CTM_CHUNK, CT_BUCKET_BITS, CTM_EPT);
+        else if (kind == JK_CT_HALF_MID) LAUNCH_CT_N(CTH_THREADS, CTHM_CHUNK, CTH_BUCKET_BITS, CTM_EPT);
         else LAUNCH_CT_N(CT_THREADS, CT_CHUNK, CT_BUCKET_BITS, CT_EPT);     // JK_CT (the host never asks for another kind here)
 #undef LAUNCH_BKT_N
 #undef LAUNCH_CT_N
@@ -2470,6 +2474,12 @@ void launch_join(hipStream_t st, const void *d_R, const u64 *d_startR, const voi
         hipLaunchKernelGGL((k_join_bkt<BJ2_THREADS, BJ2_CHUNK, BJ2_BUCKET_BITS, BJ2_EPT, false>), dim3(grid), dim3(BJ2_THREADS),
                            bj_lds_bytes(BJ2_THREADS, BJ2_CHUNK, BJ2_BUCKET_BITS), st, vR, vS,
                            d_tasks, d_ntasks, radix_bits, (Pair *)d_out, out_capacity, d_out_count, DirectJoin{});
+        return;
+    }
+    if (kind == JK_CT_HALF_MID) {
+        hipLaunchKernelGGL((k_join_ct<CTH_THREADS, CTHM_CHUNK, CTH_BUCKET_BITS, CTM_EPT, false, false>), dim3(grid), dim3(CTH_THREADS),
+                           ct_lds_bytes(CTH_THREADS, CTHM_CHUNK, CTH_BUCKET_BITS), st, vR, vS, d_tasks,
+                           d_ntasks, radix_bits, (Pair *)d_out, out_capacity, d_out_count, (u64 *)nullptr, 0u, (const u32 *)nullptr);
         return;
     }
     if (kind == JK_CT_MID) {

@@ -18,14 +18,14 @@ from radixhashjoin_amd import Engine, Opts
 from radixhashjoin_amd.binding import GEN_CONST, GEN_R, GEN_S_UNIFORM, GEN_S_ZIPF
 
 pytestmark = pytest.mark.gpu
-BKT_BIG, CT, CT_HALF, CT_WIDE, CT_HALF_WIDE, CT_MID = 1, 2, 3, 4, 5, 6
+BKT_BIG, CT, CT_HALF, CT_WIDE, CT_HALF_WIDE, CT_MID, CT_HALF_MID = 1, 2, 3, 4, 5, 6, 7
 
 
 @pytest.fixture(scope="module", params=[(BKT_BIG, 0), (CT, 0), (CT_HALF, 0), (CT, 1), (CT, 2), (CT_HALF, 2), (CT_WIDE, 2), (CT_HALF_WIDE, 2),
-                                        (CT_MID, 0), (CT_MID, 2)],
+                                        (CT_MID, 0), (CT_MID, 2), (CT_HALF_MID, 2)],
                 ids=["bkt_big", "compact_table", "compact_table_half", "compact_table_narrow1", "compact_table_narrow2",
                      "compact_table_half_narrow2", "compact_table_20slots_narrow2", "compact_table_half_20slots_narrow2",
-                     "compact_table_mid", "compact_table_mid_narrow2"])
+                     "compact_table_mid", "compact_table_mid_narrow2", "compact_table_half_mid_narrow2"])
 def big(request):
     e = Engine(0)
     e.set_option("join.big_tables", 1)
@@ -75,6 +75,7 @@ def check(engine, oracle, R, S, plan, wide_rowids=False):
                                         (17_921, 16_385, 1),         # one tuple beyond each
                                         (17_000, 20_480, 1), (8_900, 10_241, 1),   # the 20-slot tasks: exactly one, one beyond
                                         (12_288, 12_288, 1), (12_289, 12_289, 1),  # the 12288-entry geometry: exactly, one beyond
+                                        (6_144, 6_144, 1), (6_145, 6_145, 1),      # ... and its half-size form
                                         (300_000, 300_000, 1500)])   # 200-tuple partitions through the same kernels
 def test_pkfk_16_bit_plan(big, oracle, nR, nS, nlow):
     rng = np.random.default_rng(nR + nS)

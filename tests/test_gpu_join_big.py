@@ -21,17 +21,31 @@ pytestmark = pytest.mark.gpu
 BKT_BIG, CT, CT_HALF, CT_WIDE, CT_HALF_WIDE, CT_MID, CT_HALF_MID = 1, 2, 3, 4, 5, 6, 7
 
 
-@pytest.fixture(scope="module", params=[(BKT_BIG, 0), (CT, 0), (CT_HALF, 0), (CT, 1), (CT, 2), (CT_HALF, 2), (CT_WIDE, 2), (CT_HALF_WIDE, 2),
-                                        (CT_MID, 0), (CT_MID, 2), (CT_HALF_MID, 2)],
-                ids=["bkt_big", "compact_table", "compact_table_half", "compact_table_narrow1", "compact_table_narrow2",
-                     "compact_table_half_narrow2", "compact_table_20slots_narrow2", "compact_table_half_20slots_narrow2",
-                     "compact_table_mid", "compact_table_mid_narrow2", "compact_table_half_mid_narrow2"])
-def big(request):
+def _forced(param):
     e = Engine(0)
     e.set_option("join.big_tables", 1)
-    e.set_option("join.big_kernel", request.param[0])
-    e.narrow = request.param[1]
+    e.set_option("join.big_kernel", param[0])
+    e.narrow = param[1]
     e.set_option("partition.narrow", e.narrow)
+    return e
+
+
+@pytest.fixture(scope="module", params=[(BKT_BIG, 0), (CT, 0), (CT_HALF, 0), (CT, 1), (CT, 2), (CT_HALF, 2)],
+                ids=["bkt_big", "compact_table", "compact_table_half", "compact_table_narrow1", "compact_table_narrow2",
+                     "compact_table_half_narrow2"])
+def big(request):
+    e = _forced(request.param)
+    yield e
+    e.close()
+
+
+# the geometries added in round 3 (same kernel template, other table size / slot rows): a shorter list of cases, chosen at
+# their table and task boundaries, plus duplicates, long buckets and the 17-18-bit plans
+@pytest.fixture(scope="module", params=[(CT_WIDE, 2), (CT_HALF_WIDE, 2), (CT_MID, 0), (CT_MID, 2), (CT_HALF_MID, 2)],
+                ids=["compact_table_20slots_narrow2", "compact_table_half_20slots_narrow2", "compact_table_mid",
+                     "compact_table_mid_narrow2", "compact_table_half_mid_narrow2"])
+def geom(request):
+    e = _forced(request.param)
     yield e
     e.close()
 
@@ -73,17 +87,33 @@ def check(engine, oracle, R, S, plan, wide_rowids=False):
                                         (200_000, 50_000, 4),        # build on S (the smaller bucket), pairs stay (rowR,rowS)
                                         (17_920, 16_384, 1),         # exactly one table, exactly one task
                                         (17_921, 16_385, 1),         # one tuple beyond each
-                                        (17_000, 20_480, 1), (8_900, 10_241, 1),   # the 20-slot tasks: exactly one, one beyond
-                                        (12_288, 12_288, 1), (12_289, 12_289, 1),  # the 12288-entry geometry: exactly, one beyond
-                                        (6_144, 6_144, 1), (6_145, 6_145, 1),      # ... and its half-size form
                                         (300_000, 300_000, 1500)])   # 200-tuple partitions through the same kernels
 def test_pkfk_16_bit_plan(big, oracle, nR, nS, nlow):
+    pkfk_case(big, oracle, nR, nS, nlow)
+
+
+def pkfk_case(eng, oracle, nR, nS, nlow, plan=None):
     rng = np.random.default_rng(nR + nS)
     rv = rng.permutation(1 << 22)[:nR].astype(np.uint64)
     R = rel(rng, nR, few_partitions(rv, nlow))
     S = rel(rng, nS, R["payload"][rng.integers(0, nR, nS)], key0=1 << 31)
     S["payload"][::97] ^= np.uint64(1 << 40)                        # some probe tuples match nothing
-    check(big, oracle, R, S, Opts(2, 8, 8))
+    check(eng, oracle, R, S, plan or Opts(2, 8, 8))
+
+
+@pytest.mark.parametrize("nR,nS,nlow", [(60_000, 200_000, 3),                     # chunks and several tasks per partition
+                                        (17_000, 20_480, 1), (8_900, 10_241, 1),   # the 20-slot tasks: exactly one, one beyond
+                                        (12_288, 12_288, 1), (12_289, 12_289, 1),  # the 12288-entry geometry: exactly, one beyond
+                                        (6_144, 6_144, 1), (6_145, 6_145, 1),      # ... and its half-size form
+                                        (200_000, 50_000, 4)])                     # build on S, pairs stay (rowR,rowS)
+def test_pkfk_16_bit_plan_new_geometries(geom, oracle, nR, nS, nlow):
+    pkfk_case(geom, oracle, nR, nS, nlow)
+
+
+def test_new_geometries_duplicates_long_buckets_and_deep_plans(geom, oracle):
+    test_duplicates_on_both_sides(geom, oracle)
+    test_long_buckets_cooperative_scan(geom, oracle)
+    test_17_and_18_bit_plans_narrow(geom, oracle, Opts(2, 8, 9))
 
 
 @pytest.mark.parametrize("plan", [Opts(2, 8, 8), Opts(2, 9, 9), Opts(2, 9, 8), Opts(2, 8, 9), Opts(2, 10, 10)])

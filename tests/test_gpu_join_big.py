@@ -186,7 +186,8 @@ def test_all_equal_keys(big):
 def test_full_width_rowids(big, oracle):
     rng = np.random.default_rng(3)
     n = 50_000
-    R = rel(rng, n, few_partitions(rng.permutation(1 << 30)[:n].astype(np.uint64), 2))
+    vals = rng.permutation(np.unique(rng.integers(0, 1 << 30, 2 * n)))[:n].astype(np.uint64)     # n distinct values below 2^30
+    R = rel(rng, n, few_partitions(vals, 2))
     R["key"] = rng.integers(0, 1 << 63, n, dtype=np.uint64) * np.uint64(2) + np.uint64(1)
     S = rel(rng, 80_000, R["payload"][rng.integers(0, n, 80_000)])
     S["key"] = rng.integers(0, 1 << 63, 80_000, dtype=np.uint64) * np.uint64(2)

@@ -26,9 +26,11 @@ def test_reference_code_drives_gpu_join(tmp_path, small_joins):
         pytest.skip(f"not built (needs the reference checkout at build time): {missing}")
     stdin = open(os.path.join(GOLD, "small", "small.init"), "rb").read() + open(os.path.join(GOLD, "small", "small.work"), "rb").read()
     expected = open(os.path.join(GOLD, "small", "small.result"), "rb").read()
-    # one binary after the other (a box has one GPU), each through communicate(): both pipes are drained while the child
-    # runs, so a child that writes more than a pipe buffer to stderr cannot block, and the timeout covers the whole exchange
-    for b, p in paths.items():
+    # the three binaries side by side (most of their minute is the reference's own CPU code above the seam), each driven by
+    # communicate() in its own thread: both pipes are drained while the child runs, so a child that writes more than a pipe
+    # buffer to stderr cannot block, and the timeout covers the whole exchange
+    def run(item):
+        b, p = item
         env = dict(os.environ, RHJ_SEAM_LOG=str(tmp_path / f"{b}.log"))
         pr = subprocess.Popen([p], stdin=subprocess.PIPE, stdout=subprocess.PIPE, stderr=subprocess.PIPE, cwd=GOLD, env=env)
         try:
@@ -37,8 +39,13 @@ def test_reference_code_drives_gpu_join(tmp_path, small_joins):
             pr.kill()
             pr.communicate()
             raise
-        assert pr.returncode == 0, (b, err[-2000:])
-        assert out == expected, b                                 # 50 lines of SUMs / NULLs, byte-identical
+        return b, pr.returncode, out, err
+
+    import concurrent.futures
+    with concurrent.futures.ThreadPoolExecutor(max_workers=len(paths)) as pool:
+        for b, rc, out, err in pool.map(run, paths.items()):
+            assert rc == 0, (b, err[-2000:])
+            assert out == expected, b                             # 50 lines of SUMs / NULLs, byte-identical
     # the seam binary logs every call that went through rhj_join: the same 94 joins the CPU reference makes
     meta, _ = small_joins
     want = collections.Counter((c["nR"], c["nS"], c["count"]) for c in meta)

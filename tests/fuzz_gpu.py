@@ -2,9 +2,9 @@
 """tests/fuzz_gpu.py -- randomized differential test of the HIP path against the CPU oracle (run by hand on the GPU box).
 Random sizes (incl. tile/unit/table boundaries), value domains, duplicate structure, skew, radix plans and
 probe splits; compares (count, checksum) and, for small outputs, the sorted pair sets.  python tests/fuzz_gpu.py [seconds] [seed]
-RHJ_FUZZ_BIG=1|2|3 forces the oversized-partition kernels (1: chunked 16-byte entries, 2 / 3: compact table at full / half
-size where the plan allows); with RHJ_FUZZ_NARROW=1 half of the cases run the fused 8+8 plan, the one that stores its
-partitions in the narrow {payload, rowID} format (rowIDs start at 10^7 on S; every 16th case has one rowID >= 2^32, which must
+RHJ_FUZZ_BIG=1..7 forces the oversized-partition kernels (1: chunked 16-byte entries, 2 / 3: compact table at full / half
+size where the plan allows, 4 / 5 with 20 probe slots, 6 / 7 the 12288- / 6144-entry geometries); with RHJ_FUZZ_NARROW=1 half of
+the cases run a 16-, 17- or 18-bit plan that stores its partitions in the narrow {payload, rowID} format (rowIDs start at 10^7 on S; every 16th case has one rowID >= 2^32, which must
 send the join back to 16-byte tuples)."""
 import os, sys, time
 import numpy as np
@@ -74,8 +74,11 @@ while time.time() - t0 < budget:
             (R if rng.random() < 0.5 else S)["key"][int(rng.integers(0, min(nR, nS)))] = np.uint64(1 << 32) + np.uint64(cases)
             wide = True
             exp_n, exp_c = o.join_count_checksum(R, S)
-    if r == 2.0:
-        opts = rhj.Opts(2, 8, 8, int(rng.choice([0, 4096, 32768])))
+    if r == 2.0:                                                             # 16 bits fused, or a 17-18-bit plan (narrow level 2 only)
+        b1, b2 = [(8, 8), (8, 8), (8, 9), (9, 8), (9, 9)][int(rng.integers(0, 5))]
+        if b1 + b2 > 16:
+            e.set_option("partition.narrow", 2)
+        opts = rhj.Opts(2, b1, b2, int(rng.choice([0, 4096, 32768])))
     elif r < 0.4:
         opts = None
     elif r < 0.55:

@@ -149,3 +149,32 @@ def test_shard_split_refuses_a_base_that_does_not_fit(engine):
     with pytest.raises(RhjError):
         engine.shard_split(0, d, len(t), SHIFT, BITS, kmin + 1, buf)          # base above the smallest rowID
     d.free(); buf.free()
+
+
+def test_lopsided_segments(oracle):
+    """every owner receives (nearly) everything from ONE sender and nothing from the others: empty sender segments, empty
+    pass-1 units, sizes far from n / world"""
+    world, n_per = 4, 50_000
+    rng = np.random.default_rng(77)
+    Rs, Ss = [], []
+    for r in range(world):
+        # class = payload bits [20, 28) = value bits [4, 12): shard r only has classes [64 r, 64 r + 64)
+        hi = rng.permutation(1 << 12)[:n_per // 8].astype(np.uint64)                     # value bits [12, 24)
+        vals = (hi[rng.integers(0, len(hi), n_per)] << np.uint64(12)) | (np.uint64(64 * r) + rng.integers(0, 64, n_per).astype(np.uint64)) << np.uint64(4) \
+            | rng.integers(0, 16, n_per).astype(np.uint64)
+        for dst, v in ((Rs, vals), (Ss, vals[rng.permutation(n_per)])):
+            t = np.empty(n_per, dtype=TUPLE)
+            t["key"] = rng.permutation(n_per).astype(np.uint64) + np.uint64(r * (5 << 30))
+            t["payload"] = (v << np.uint64(16)) | np.uint64(0xBEEF)
+            dst.append(t)
+    mode, plan = shard_plan(n_per, n_per, Opts(2, 8, 8))
+    eng = Engine(0)
+    try:
+        got = sharded_join(eng, Rs, Ss, plan, SHARD_TAGGED)
+    finally:
+        eng.close()
+    exp = oracle.join(np.concatenate(Rs), np.concatenate(Ss))
+    assert len(got) == len(exp)
+    a = got[np.lexsort((got[:, 1], got[:, 0]))]
+    e = np.stack([exp["keyR"], exp["keyS"]], axis=1)
+    assert np.array_equal(a, e[np.lexsort((e[:, 1], e[:, 0]))])

@@ -184,8 +184,8 @@ int rhj_bucket_join(rhj_ctx *ctx, const rhj_tuple *d_Rp, const uint64_t *d_start
  * rhj_shard_plan returns RHJ_SHARD_TAGGED or RHJ_SHARD_GLOBAL16 for sizes / plans that fit this path (the host may use
  * RHJ_SHARD_PLAIN instead when the gathered rowID ranges allow it), or 0: fall back to exchanging 16-byte tuples
  * (rhj_partition_at + all-to-all + rhj_join_dev).
- * Limits: at most 16 ranks (nseg), class bits <= 8, fewer than 2^32 tuples received per relation, a two-pass local plan of
- * at most 16 radix bits (receivers beyond 1.1 * 10^9 tuples take the fallback). */
+ * Limits: at most 16 ranks (nseg), class bits <= 8, fewer than 2^32 tuples received per relation, a two-pass local plan;
+ * 17-18-bit plans (receivers beyond 1.1 * 10^9 tuples) only as RHJ_SHARD_PLAIN, which is what rhj_shard_plan returns for them. */
 #define RHJ_SHARD_TAGGED 1
 #define RHJ_SHARD_GLOBAL16 2
 #define RHJ_SHARD_PLAIN 3

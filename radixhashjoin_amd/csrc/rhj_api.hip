@@ -611,7 +611,9 @@ int partition_relation_fused(rhj_ctx *ctx, const void *d_in, u64 n, int b1, int 
 // Two narrow passes with SEPARATE histograms (plans of 17-18 bits: 2^(b1+b2) packed counters do not fit the LDS, so the
 // histogram of pass 2 is a second read -- of the narrow intermediate, 8 B/tuple): 16-byte tuples -> narrow part_tmp -> narrow
 // d_out.  A rowID >= 2^32 raises ctx->narrow_flag in pass 1 (every later kernel of the join returns at once).
-int partition_relation_narrow2(rhj_ctx *ctx, const void *d_in, u64 n, int b1, int b2, void *d_out, u64 *d_ps)
+// d_inK != nullptr: the input is narrow already (d_in = payloads, d_inK = rowIDs: a received shard whose rowIDs are global).
+int partition_relation_narrow2(rhj_ctx *ctx, const void *d_in, u64 n, int b1, int b2, void *d_out, u64 *d_ps,
+                               const u32 *d_inK = nullptr)
 {
     RHJCHK(ensure(ctx, ctx->seg0, 64));
     RHJCHK(ensure(ctx, ctx->part_tmp, (size_t)(n ? n : 1) * 16));
@@ -636,8 +638,8 @@ int partition_relation_narrow2(rhj_ctx *ctx, const void *d_in, u64 n, int b1, in
         }
         {
             Span s(ctx, RHJ_K_HIST);
-            if (!pass) launch_hist_units(ctx->stream, d_in, g, seg_start, unit_start, (u32 *)ctx->unit_hist.p);
-            else launch_hist_units_narrow(ctx->stream, ctx->part_tmp.p, g, seg_start, unit_start, (u32 *)ctx->unit_hist.p);
+            if (!pass && !d_inK) launch_hist_units(ctx->stream, d_in, g, seg_start, unit_start, (u32 *)ctx->unit_hist.p);
+            else launch_hist_units_narrow(ctx->stream, pass ? ctx->part_tmp.p : d_in, g, seg_start, unit_start, (u32 *)ctx->unit_hist.p);
         }
         {
             Span s(ctx, RHJ_K_SCAN);
@@ -648,7 +650,7 @@ int partition_relation_narrow2(rhj_ctx *ctx, const void *d_in, u64 n, int b1, in
             Span s(ctx, RHJ_K_SCATTER);
             void *out = pass ? d_out : ctx->part_tmp.p;
             launch_scatter_units_narrow_any(ctx->stream, pass ? ctx->part_tmp.p : d_in,
-                                            pass ? (const u32 *)((const unsigned char *)ctx->part_tmp.p + narrow_k_offset(n)) : nullptr,
+                                            pass ? (const u32 *)((const unsigned char *)ctx->part_tmp.p + narrow_k_offset(n)) : d_inK,
                                             out, (u32 *)((unsigned char *)out + narrow_k_offset(n)), g, seg_start, unit_start,
                                             (const u64 *)ctx->unit_base.p, wide);
         }
@@ -1651,8 +1653,10 @@ int rhj_shard_plan(uint64_t nR, uint64_t nS, const rhj_opts *in, rhj_opts *resol
     rhj_opts o;
     if (resolve_plan(nR, nS, in, &o, true) != RHJ_OK) return RHJ_E_INVALID;
     *resolved = o;
-    if (o.passes != 2 || !fused_two_pass_ok(o.bits1, o.bits2) || !narrow_pass_ok(o.bits1) || !narrow_pass_ok(o.bits2)) return 0;
-    if (o.bits1 < tag_bits() || nR < NARROW_MIN_TUPLES || nS < NARROW_MIN_TUPLES || nR >= ((u64)1 << 32) || nS >= ((u64)1 << 32)) return 0;
+    if (o.passes != 2 || nR < NARROW_MIN_TUPLES || nS < NARROW_MIN_TUPLES || nR >= ((u64)1 << 32) || nS >= ((u64)1 << 32)) return 0;
+    if (!narrow_fused_plan(o))                          // 17-18 bits: no sender-aligned pass-2 units, so only rowIDs that need no restoring
+        return o.bits1 + o.bits2 > 16 && narrow_pass9_ok(o.bits1) && narrow_pass9_ok(o.bits2) ? RHJ_SHARD_PLAIN : 0;
+    if (o.bits1 < tag_bits()) return 0;
     rhj_ctx probe;                                      // default options: which kernel would join partitions of this size
     const int tb = o.bits1 + o.bits2;
     const int kind = choose_join_kind(&probe, nR, nS, (u64)1 << tb, tb);
@@ -1750,9 +1754,10 @@ int rhj_shard_partition(rhj_ctx *ctx, int side, const uint64_t *d_payloads, cons
     if (mode == RHJ_SHARD_PLAIN)
         for (int i = 0; i < nseg; i++)
             if (row0[i] != 0) return fail(ctx, RHJ_E_INVALID, "RHJ_SHARD_PLAIN: every rank must have split with key_base 0");
-    if (!fused_two_pass_ok(plan->bits1, plan->bits2) || !narrow_pass_ok(plan->bits1) || !narrow_pass_ok(plan->bits2) ||
-        plan->bits1 < tag_bits() || m >= ((u64)1 << 32))
-        return fail(ctx, RHJ_E_INVALID, "rhj_shard_partition: not a plan of the narrow format (see rhj_shard_plan)");
+    const bool fused = narrow_fused_plan(*plan) && plan->bits1 >= tag_bits();
+    const bool deep = !narrow_fused_plan(*plan) && plan->bits1 + plan->bits2 > 16 && narrow_pass9_ok(plan->bits1) && narrow_pass9_ok(plan->bits2);
+    if (!(fused || (deep && mode == RHJ_SHARD_PLAIN)) || m >= ((u64)1 << 32))
+        return fail(ctx, RHJ_E_INVALID, "rhj_shard_partition: not a plan of the narrow format for this mode (see rhj_shard_plan)");
     for (int i = 0; i < nseg; i++)
         if (seg_off[i] > seg_off[i + 1]) return fail(ctx, RHJ_E_INVALID, "rhj_shard_partition: segment offsets must not decrease");
     prof_reset(ctx);
@@ -1783,7 +1788,8 @@ int rhj_shard_partition(rhj_ctx *ctx, int side, const uint64_t *d_payloads, cons
         in.seg_off = (const u64 *)seg_off;
         in.final_form = mode == RHJ_SHARD_TAGGED ? 1 : mode == RHJ_SHARD_GLOBAL16 ? 2 : 0;
         in.key_bases = d_bases;
-        RHJCHK(partition_relation_fused(ctx, in, m, plan->bits1, plan->bits2, part.p, (u64 *)ps.p, 2));
+        if (fused) RHJCHK(partition_relation_fused(ctx, in, m, plan->bits1, plan->bits2, part.p, (u64 *)ps.p, 2));
+        else RHJCHK(partition_relation_narrow2(ctx, d_payloads, m, plan->bits1, plan->bits2, part.p, (u64 *)ps.p, (const u32 *)d_rowids));
     }
     ctx->shard_side_done[side] = true;
     ctx->shard_n[side] = m;

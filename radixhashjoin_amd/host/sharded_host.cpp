@@ -130,7 +130,7 @@ int main(int argc, char **argv)
     }
     rhj_opts plan;
     int mode = rhj_shard_plan(maxrecv[0], maxrecv[1], nullptr, &plan);     // from the LARGEST receive: the same bits on all ranks
-    if (mode <= 0) { fprintf(stderr, "sizes outside the narrow sharded path: exchange 16-byte tuples instead\n"); return 3; }
+    if (mode <= 0 || (mode == RHJ_SHARD_PLAIN && !small)) { fprintf(stderr, "sizes outside the narrow sharded path: exchange 16-byte tuples instead\n"); return 3; }
     if (small) mode = RHJ_SHARD_PLAIN;
     uint64_t row0[2][16] = {{0}};
     for (int rel = 0; rel < 2; rel++) for (int r = 0; r < world; r++) row0[rel][r] = small ? 0 : all[(size_t)r * words + 2 + 2 * rel];

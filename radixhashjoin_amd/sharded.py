@@ -142,9 +142,12 @@ class ShardedJoin:
             from .binding import SHARD_PLAIN, shard_plan
             mode, plan = shard_plan(max(meta["recvR"]), max(meta["recvS"]), self.local_opts)
             # rowIDs that are all below 2^32 travel as they are (key_base 0 on every rank): the receiver has nothing to restore
-            if mode and self.rowid_mode:
+            small = all(_u64(head[r][3]) < (1 << 32) and _u64(head[r][5]) < (1 << 32) for r in range(self.world))
+            if mode == SHARD_PLAIN and not small:
+                mode = 0                               # a 17-18-bit local plan cannot restore rowIDs: 16-byte fallback
+            elif mode and self.rowid_mode and mode != SHARD_PLAIN:
                 mode = self.rowid_mode
-            elif mode and all(_u64(head[r][3]) < (1 << 32) and _u64(head[r][5]) < (1 << 32) for r in range(self.world)):
+            elif mode and small:
                 mode = SHARD_PLAIN
         if not mode:
             return self._join_tuple16(R, nR, S, nS, inR, outR, inS, outS, out)

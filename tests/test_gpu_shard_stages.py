@@ -112,12 +112,14 @@ def global_relations(rng, world, n_per, nlow, dup, stride=5 << 30):
     (3, 40_000, 0, 2, Opts(2, 6, 6), BKT, SHARD_GLOBAL16),         # 16-byte final partitions into the one-table kernel works too
     (4, 30_000, 5, 1, Opts(2, 8, 8), CT, SHARD_PLAIN),             # rowIDs below 2^32: narrow end to end, nothing to restore
     (3, 50_000, 0, 2, Opts(2, 5, 5), BKT, SHARD_PLAIN),
+    (3, 40_000, 4, 1, Opts(2, 8, 9), CT, SHARD_PLAIN),             # 17- and 18-bit local plans (receivers beyond 1.1 * 10^9): PLAIN only
+    (2, 30_000, 0, 2, Opts(2, 9, 9), BKT, SHARD_PLAIN),
 ])
 def test_shard_stage_calls_equal_global_join(oracle, world, n_per, nlow, dup, plan, kernel, mode):
     rng = np.random.default_rng(world * 1000 + n_per)
     Rs, Ss = global_relations(rng, world, n_per, nlow, dup, stride=(1 << 30) if mode == SHARD_PLAIN else (5 << 30))
     suggested, rplan = shard_plan(n_per, n_per, plan)
-    assert suggested == SHARD_TAGGED                # (sizes this small: one table per partition)
+    assert suggested == (SHARD_PLAIN if plan.bits1 + plan.bits2 > 16 else SHARD_TAGGED)    # (sizes this small: one table per partition)
     eng = Engine(0)
     try:
         if kernel != BKT:

@@ -16,6 +16,19 @@ def test_query_layer_unit_checks():
     assert "all checks passed" in r.stdout
 
 
+def test_scheduler_mirror_survives_start_stop_stress():
+    """radixhashjoin_amd/host/sched_stress.cpp: 20000 schedulers started and stopped at once (idle workers: the window in
+    which the reference's lock-free `done = true` in JobScheduler::stop, JobScheduler.cpp:140-146, loses its wake-up -- see
+    oracle/ref_sched_race.cpp), every eighth one with jobs, a barrier and jobs still queued at stop()"""
+    exe = os.path.join(HOST, "sched_stress")
+    if not os.path.exists(exe):
+        r = subprocess.run(["make", "-s", "-C", HOST, "sched_stress"], capture_output=True, text=True)
+        assert r.returncode == 0, r.stdout + r.stderr
+    r = subprocess.run([exe, "20000", "4"], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stderr
+    assert r.stdout.startswith("ok 20000 cycles")
+
+
 def test_host_binaries_built():
     for name in ("librhj_compat.a", "host_driver", "join_gpu"):
         assert os.path.exists(os.path.join(HOST, name)), name

@@ -681,8 +681,8 @@ int choose_join_kind(const rhj_ctx *ctx, u64 nR, u64 nS, u64 nparts, int radix_b
     const u64 nbuild = nR < nS ? nR : nS;
     if (!(ctx->opt_big_tables == 1 || (ctx->opt_big_tables < 0 && nbuild / nparts > (u64)BJ_CHUNK))) return JK_BKT;
     if (radix_bits < join_ct_min_radix_bits() || ctx->opt_big_kernel == JK_BKT_BIG) return JK_BKT_BIG;
-    if (ctx->opt_big_kernel == JK_CT || ctx->opt_big_kernel == JK_CT_HALF || ctx->opt_big_kernel == JK_CT_MID || ctx->opt_big_kernel == JK_CT_HALF_MID) return ctx->opt_big_kernel;
-    if (ctx->opt_big_kernel == JK_CT_WIDE) return narrow ? JK_CT_WIDE : JK_CT;
+    if (jk_is_ct(ctx->opt_big_kernel) && !jk_ct_narrow_only(ctx->opt_big_kernel)) return ctx->opt_big_kernel;
+    if (ctx->opt_big_kernel == JK_CT_WIDE) return narrow ? JK_CT_WIDE : JK_CT_13;
     if (ctx->opt_big_kernel == JK_CT_HALF_WIDE) return narrow ? JK_CT_HALF_WIDE : JK_CT_HALF;
     // the compact-table kernel at half size (two workgroups per CU) while the average partition fits its table
     // AND its 8192-tuple probe tasks (a partition cut into two tasks builds its table twice)
@@ -694,9 +694,10 @@ int choose_join_kind(const rhj_ctx *ctx, u64 nR, u64 nS, u64 nparts, int radix_b
     // table twice: [measured] 2.2 * 10^9 x 2.2 * 10^9, join kernel 32.5 ms with two 16-slot tasks per partition
     if (narrow && fits(JK_CT_HALF_WIDE)) return JK_CT_HALF_WIDE;
     if (fits(JK_CT_MID)) return JK_CT_MID;           // 12 + 12 slot rows instead of 18 + 16 for partitions of up to 11.5 K tuples
-    if (fits(JK_CT)) return JK_CT;
+    if (fits(JK_CT)) return JK_CT;                   // 16352 entries in 16384 buckets (up to 1.005 * 10^9 tuples under 16 bits)
+    if (fits(JK_CT_13)) return JK_CT_13;             // 17920 entries in 8192 buckets
     if (narrow && fits(JK_CT_WIDE)) return JK_CT_WIDE;
-    return JK_CT;
+    return JK_CT_13;
 }
 
 bool narrow_fused_plan(const rhj_opts &plan)
@@ -822,7 +823,7 @@ int join_phase_on(rhj_ctx *ctx, const void *d_Rp, const u64 *d_psR, u64 nR, cons
     // a task addresses its build range with 32 bits; k_make_tasks reports any partition whose build side is larger
     // (counters[5], checked below) whatever the plan
     const int kind = choose_join_kind(ctx, nR, nS, nparts, radix_bits, narrow);
-    if (narrow && kind != JK_CT && kind != JK_CT_HALF && kind != JK_BKT && kind != JK_CT_WIDE && kind != JK_CT_HALF_WIDE && kind != JK_CT_MID && kind != JK_CT_HALF_MID)
+    if (narrow && kind != JK_BKT && !jk_is_ct(kind))
         return fail(ctx, RHJ_E_INVALID, "no bucket-join kernel for narrow partitions under this plan");
     if (join_probe_split(kind) && probe_split > join_probe_split(kind)) probe_split = join_probe_split(kind);
     const u64 max_tasks64 = nparts + (nR + nS) / probe_split + 1;
@@ -842,7 +843,7 @@ int join_phase_on(rhj_ctx *ctx, const void *d_Rp, const u64 *d_psR, u64 nR, cons
     ctx->counters_clean = false;
     const bool direct = allow_direct && !narrow && is_direct(ctx, nparts, nR, nS);
     ctx->last_join_kind = direct ? -1 : kind;
-    if (check_radix && !direct && (kind == JK_CT || kind == JK_CT_HALF || kind == JK_CT_MID || kind == JK_CT_HALF_MID)) {       // counters[6]: the partitions break the radix_bits contract
+    if (check_radix && !direct && jk_is_ct(kind)) {       // counters[6]: the partitions break the radix_bits contract
         Span s(ctx, RHJ_K_AUX);
         launch_check_radix(ctx->stream, d_Rp, d_psR, d_Sp, d_psS, nparts, radix_bits, d_count + 6);
     }
@@ -1041,7 +1042,7 @@ int rhj_set_option(rhj_ctx *ctx, const char *name, int64_t value)
     if (!ctx || !name) return fail(ctx, RHJ_E_INVALID, "rhj_set_option: null argument");
     const std::string n(name);
     if (n == "join.big_tables" && value >= -1 && value <= 1) { ctx->opt_big_tables = (int)value; return RHJ_OK; }
-    if (n == "join.big_kernel" && (value == -1 || (value >= JK_BKT_BIG && value <= JK_CT_HALF_MID))) {
+    if (n == "join.big_kernel" && (value == -1 || (value >= JK_BKT_BIG && value <= JK_LAST))) {
         ctx->opt_big_kernel = (int)value;
         return RHJ_OK;
     }
@@ -1661,7 +1662,7 @@ int rhj_shard_plan(uint64_t nR, uint64_t nS, const rhj_opts *in, rhj_opts *resol
     const int tb = o.bits1 + o.bits2;
     const int kind = choose_join_kind(&probe, nR, nS, (u64)1 << tb, tb);
     if (kind == JK_BKT) return RHJ_SHARD_TAGGED;
-    if (kind == JK_CT || kind == JK_CT_HALF || kind == JK_CT_MID || kind == JK_CT_HALF_MID) return RHJ_SHARD_GLOBAL16;
+    if (jk_is_ct(kind) && !jk_ct_narrow_only(kind)) return RHJ_SHARD_GLOBAL16;
     return 0;
 }
 

@@ -1624,7 +1624,11 @@ k_join_bkt(const RelView<NARROW> R, const RelView<NARROW> S, const JoinTask *__r
 // Bucket counts are 16-bit halves of 32-bit LDS words (ds_add_rtn on the word; a half cannot carry: <= 17920 per
 // workgroup), so 8192 buckets cost 16 KiB and the average bucket holds 1.9 entries.
 // ------------------------------------------------------------------------------------------------
-constexpr int CT_THREADS = 1024, CT_CHUNK = 17920, CT_BUCKET_BITS = 13, CT_EPT = 16, CT_PT = 4, CT_DEPTH = 3;
+constexpr int CT_THREADS = 1024, CT_CHUNK = 16352, CT_BUCKET_BITS = 14, CT_EPT = 16, CT_PT = 4, CT_DEPTH = 3;
+// JK_CT_13 (the full-size geometry of rounds 2 and 3 until the bucket count was doubled): 17920 entries, 8192 buckets.  For
+// partitions of 15.3 - 16.8 K build tuples (1.005 - 1.1 * 10^9 tuples under 16 bits), which the 16352-entry table would
+// build in two chunks; the 20-slot kernel (probe side beyond 16 K) keeps this table too.
+constexpr int CT13_CHUNK = 17920, CT13_BUCKET_BITS = 13;
 // the same kernel at half size, for partitions of up to 8960 build tuples (3 ... 5.5 * 10^8 tuples under a 16-bit plan):
 // 512 threads, 80 KiB LDS -> TWO workgroups per CU, which overlap each other's memory and LDS phases; the per-thread
 // register picture (18 build slots, 16 probe slots, 128 VGPRs) is unchanged.  The kernel's cost per task does not shrink
@@ -1639,7 +1643,7 @@ constexpr int CT_EPT_WIDE = 20;
 // kernel's cost per task follows its slot rows, not the partition: partitions of 8.4 - 11.5 K tuples (5.5 - 7.5 * 10^8 tuples under
 // 16 bits, 1.1 - 1.5 * 10^9 under 17) paid for 18 + 16 rows in the full-size geometry ([measured] join kernel 8.5 -> 6.6 ms at
 // 6 * 10^8, 17.6 -> 14.1 at 1.5 * 10^9; 16 + 16 rows for the 15.3 K-tuple partitions of 10^9 tuples: 10.09 -> 10.02, not kept).
-constexpr int CTM_CHUNK = 12288, CTM_EPT = 12;
+constexpr int CTM_CHUNK = 12288, CTM_EPT = 12, CTM_BUCKET_BITS = 14, CTHM_BUCKET_BITS = 13;
 constexpr int CTHM_CHUNK = 6144;                    // ... and at half size (512 threads, two workgroups per CU): 4.2 - 5.8 K-tuple partitions
 constexpr u32 CT_NONE = 0xFFFFu;
 constexpr int CT_MIN_RADIX_BITS = 16;       // keys must fit 48 bits
@@ -2075,13 +2079,13 @@ constexpr int BJ2_THREADS = 1024, BJ2_CHUNK = 8448, BJ2_BUCKET_BITS = 12, BJ2_EP
 // probe tuples per task / build tuples per table of each join kernel (host plan)
 u32 join_probe_split(int kind)
 {
-    return kind == JK_CT ? (u32)(CT_THREADS * CT_EPT) : kind == JK_CT_HALF ? (u32)(CTH_THREADS * CT_EPT) :
+    return kind == JK_CT || kind == JK_CT_13 ? (u32)(CT_THREADS * CT_EPT) : kind == JK_CT_HALF ? (u32)(CTH_THREADS * CT_EPT) :
            kind == JK_CT_WIDE ? (u32)(CT_THREADS * CT_EPT_WIDE) : kind == JK_CT_HALF_WIDE ? (u32)(CTH_THREADS * CT_EPT_WIDE) :
            kind == JK_CT_MID ? (u32)(CT_THREADS * CTM_EPT) : kind == JK_CT_HALF_MID ? (u32)(CTH_THREADS * CTM_EPT) : 0u;
 }
 u32 join_table_tuples(int kind)
 {
-    return kind == JK_CT || kind == JK_CT_WIDE ? (u32)CT_CHUNK : kind == JK_CT_HALF || kind == JK_CT_HALF_WIDE ? (u32)CTH_CHUNK :
+    return kind == JK_CT ? (u32)CT_CHUNK : kind == JK_CT_13 || kind == JK_CT_WIDE ? (u32)CT13_CHUNK : kind == JK_CT_HALF || kind == JK_CT_HALF_WIDE ? (u32)CTH_CHUNK :
            kind == JK_CT_MID ? (u32)CTM_CHUNK : kind == JK_CT_HALF_MID ? (u32)CTHM_CHUNK : kind == JK_BKT_BIG ? (u32)BJ2_CHUNK : (u32)BJ_CHUNK;
 }
 int join_ct_min_radix_bits() { return CT_MIN_RADIX_BITS; }
@@ -2146,11 +2150,13 @@ static void allow_big_lds()
     SET_LDS((k_join_ct<CT_THREADS, CT_CHUNK, CT_BUCKET_BITS, CT_EPT, true, false>), ct_lds_bytes());
     SET_LDS((k_join_ct<CT_THREADS, CT_CHUNK, CT_BUCKET_BITS, CT_EPT, false, true>), ct_lds_bytes());
     SET_LDS((k_join_ct<CTH_THREADS, CTH_CHUNK, CTH_BUCKET_BITS, CT_EPT, false, true>), ct_lds_bytes(CTH_THREADS, CTH_CHUNK, CTH_BUCKET_BITS));
-    SET_LDS((k_join_ct<CT_THREADS, CT_CHUNK, CT_BUCKET_BITS, CT_EPT_WIDE, false, true>), ct_lds_bytes());
-    SET_LDS((k_join_ct<CT_THREADS, CTM_CHUNK, CT_BUCKET_BITS, CTM_EPT, false, true>), ct_lds_bytes(CT_THREADS, CTM_CHUNK, CT_BUCKET_BITS));
-    SET_LDS((k_join_ct<CT_THREADS, CTM_CHUNK, CT_BUCKET_BITS, CTM_EPT, false, false>), ct_lds_bytes(CT_THREADS, CTM_CHUNK, CT_BUCKET_BITS));
-    SET_LDS((k_join_ct<CTH_THREADS, CTHM_CHUNK, CTH_BUCKET_BITS, CTM_EPT, false, true>), ct_lds_bytes(CTH_THREADS, CTHM_CHUNK, CTH_BUCKET_BITS));
-    SET_LDS((k_join_ct<CTH_THREADS, CTHM_CHUNK, CTH_BUCKET_BITS, CTM_EPT, false, false>), ct_lds_bytes(CTH_THREADS, CTHM_CHUNK, CTH_BUCKET_BITS));
+    SET_LDS((k_join_ct<CT_THREADS, CT13_CHUNK, CT13_BUCKET_BITS, CT_EPT_WIDE, false, true>), ct_lds_bytes(CT_THREADS, CT13_CHUNK, CT13_BUCKET_BITS));
+    SET_LDS((k_join_ct<CT_THREADS, CT13_CHUNK, CT13_BUCKET_BITS, CT_EPT, false, true>), ct_lds_bytes(CT_THREADS, CT13_CHUNK, CT13_BUCKET_BITS));
+    SET_LDS((k_join_ct<CT_THREADS, CT13_CHUNK, CT13_BUCKET_BITS, CT_EPT, false, false>), ct_lds_bytes(CT_THREADS, CT13_CHUNK, CT13_BUCKET_BITS));
+    SET_LDS((k_join_ct<CT_THREADS, CTM_CHUNK, CTM_BUCKET_BITS, CTM_EPT, false, true>), ct_lds_bytes(CT_THREADS, CTM_CHUNK, CTM_BUCKET_BITS));
+    SET_LDS((k_join_ct<CT_THREADS, CTM_CHUNK, CTM_BUCKET_BITS, CTM_EPT, false, false>), ct_lds_bytes(CT_THREADS, CTM_CHUNK, CTM_BUCKET_BITS));
+    SET_LDS((k_join_ct<CTH_THREADS, CTHM_CHUNK, CTHM_BUCKET_BITS, CTM_EPT, false, true>), ct_lds_bytes(CTH_THREADS, CTHM_CHUNK, CTHM_BUCKET_BITS));
+    SET_LDS((k_join_ct<CTH_THREADS, CTHM_CHUNK, CTHM_BUCKET_BITS, CTM_EPT, false, false>), ct_lds_bytes(CTH_THREADS, CTHM_CHUNK, CTHM_BUCKET_BITS));
     SET_LDS((k_join_ct<CTH_THREADS, CTH_CHUNK, CTH_BUCKET_BITS, CT_EPT_WIDE, false, true>), ct_lds_bytes(CTH_THREADS, CTH_CHUNK, CTH_BUCKET_BITS));
     SET_LDS((k_join_bkt<BJ_THREADS, BJ_CHUNK, BJ_BUCKET_BITS, BJ_EPT, false, true, true>), bj_lds_bytes(BJ_THREADS, BJ_CHUNK, BJ_BUCKET_BITS));
     SET_LDS(k_scatter_wc_n<WC_THREADS>, wc_lds_bytes(WC_MAX_BITS, WC_THREADS));
@@ -2456,9 +2462,10 @@ void launch_join(hipStream_t st, const void *d_R, const u64 *d_startR, const voi
         if (kind == JK_BKT) { if (tg) LAUNCH_BKT_N(true); else LAUNCH_BKT_N(false); }
         else if (kind == JK_CT_HALF) LAUNCH_CT_N(CTH_THREADS, CTH_CHUNK, CTH_BUCKET_BITS, CT_EPT);
         else if (kind == JK_CT_HALF_WIDE) LAUNCH_CT_N(CTH_THREADS, CTH_CHUNK, CTH_BUCKET_BITS, CT_EPT_WIDE);
-        else if (kind == JK_CT_WIDE) LAUNCH_CT_N(CT_THREADS, CT_CHUNK, CT_BUCKET_BITS, CT_EPT_WIDE);
-        else if (kind == JK_CT_MID) LAUNCH_CT_N(CT_THREADS, CTM_CHUNK, CT_BUCKET_BITS, CTM_EPT);
-        else if (kind == JK_CT_HALF_MID) LAUNCH_CT_N(CTH_THREADS, CTHM_CHUNK, CTH_BUCKET_BITS, CTM_EPT);
+        else if (kind == JK_CT_WIDE) LAUNCH_CT_N(CT_THREADS, CT13_CHUNK, CT13_BUCKET_BITS, CT_EPT_WIDE);
+        else if (kind == JK_CT_13) LAUNCH_CT_N(CT_THREADS, CT13_CHUNK, CT13_BUCKET_BITS, CT_EPT);
+        else if (kind == JK_CT_MID) LAUNCH_CT_N(CT_THREADS, CTM_CHUNK, CTM_BUCKET_BITS, CTM_EPT);
+        else if (kind == JK_CT_HALF_MID) LAUNCH_CT_N(CTH_THREADS, CTHM_CHUNK, CTHM_BUCKET_BITS, CTM_EPT);
         else LAUNCH_CT_N(CT_THREADS, CT_CHUNK, CT_BUCKET_BITS, CT_EPT);     // JK_CT (the host never asks for another kind here)
 #undef LAUNCH_BKT_N
 #undef LAUNCH_CT_N
@@ -2477,14 +2484,20 @@ void launch_join(hipStream_t st, const void *d_R, const u64 *d_startR, const voi
         return;
     }
     if (kind == JK_CT_HALF_MID) {
-        hipLaunchKernelGGL((k_join_ct<CTH_THREADS, CTHM_CHUNK, CTH_BUCKET_BITS, CTM_EPT, false, false>), dim3(grid), dim3(CTH_THREADS),
-                           ct_lds_bytes(CTH_THREADS, CTHM_CHUNK, CTH_BUCKET_BITS), st, vR, vS, d_tasks,
+        hipLaunchKernelGGL((k_join_ct<CTH_THREADS, CTHM_CHUNK, CTHM_BUCKET_BITS, CTM_EPT, false, false>), dim3(grid), dim3(CTH_THREADS),
+                           ct_lds_bytes(CTH_THREADS, CTHM_CHUNK, CTHM_BUCKET_BITS), st, vR, vS, d_tasks,
                            d_ntasks, radix_bits, (Pair *)d_out, out_capacity, d_out_count, (u64 *)nullptr, 0u, (const u32 *)nullptr);
         return;
     }
     if (kind == JK_CT_MID) {
-        hipLaunchKernelGGL((k_join_ct<CT_THREADS, CTM_CHUNK, CT_BUCKET_BITS, CTM_EPT, false, false>), dim3(grid), dim3(CT_THREADS),
-                           ct_lds_bytes(CT_THREADS, CTM_CHUNK, CT_BUCKET_BITS), st, vR, vS, d_tasks,
+        hipLaunchKernelGGL((k_join_ct<CT_THREADS, CTM_CHUNK, CTM_BUCKET_BITS, CTM_EPT, false, false>), dim3(grid), dim3(CT_THREADS),
+                           ct_lds_bytes(CT_THREADS, CTM_CHUNK, CTM_BUCKET_BITS), st, vR, vS, d_tasks,
+                           d_ntasks, radix_bits, (Pair *)d_out, out_capacity, d_out_count, (u64 *)nullptr, 0u, (const u32 *)nullptr);
+        return;
+    }
+    if (kind == JK_CT_13) {
+        hipLaunchKernelGGL((k_join_ct<CT_THREADS, CT13_CHUNK, CT13_BUCKET_BITS, CT_EPT, false, false>), dim3(grid), dim3(CT_THREADS),
+                           ct_lds_bytes(CT_THREADS, CT13_CHUNK, CT13_BUCKET_BITS), st, vR, vS, d_tasks,
                            d_ntasks, radix_bits, (Pair *)d_out, out_capacity, d_out_count, (u64 *)nullptr, 0u, (const u32 *)nullptr);
         return;
     }

@@ -18,7 +18,7 @@ from radixhashjoin_amd import Engine, Opts
 from radixhashjoin_amd.binding import GEN_CONST, GEN_R, GEN_S_UNIFORM, GEN_S_ZIPF
 
 pytestmark = pytest.mark.gpu
-BKT_BIG, CT, CT_HALF, CT_WIDE, CT_HALF_WIDE, CT_MID, CT_HALF_MID = 1, 2, 3, 4, 5, 6, 7
+BKT_BIG, CT, CT_HALF, CT_WIDE, CT_HALF_WIDE, CT_MID, CT_HALF_MID, CT_13 = 1, 2, 3, 4, 5, 6, 7, 8
 
 
 def _forced(param):
@@ -41,9 +41,10 @@ def big(request):
 
 # the geometries added in round 3 (same kernel template, other table size / slot rows): a shorter list of cases, chosen at
 # their table and task boundaries, plus duplicates, long buckets and the 17-18-bit plans
-@pytest.fixture(scope="module", params=[(CT_WIDE, 2), (CT_HALF_WIDE, 2), (CT_MID, 0), (CT_MID, 2), (CT_HALF_MID, 2)],
+@pytest.fixture(scope="module", params=[(CT_WIDE, 2), (CT_HALF_WIDE, 2), (CT_MID, 0), (CT_MID, 2), (CT_HALF_MID, 2), (CT_13, 0), (CT_13, 2)],
                 ids=["compact_table_20slots_narrow2", "compact_table_half_20slots_narrow2", "compact_table_mid",
-                     "compact_table_mid_narrow2", "compact_table_half_mid_narrow2"])
+                     "compact_table_mid_narrow2", "compact_table_half_mid_narrow2", "compact_table_8192_buckets",
+                     "compact_table_8192_buckets_narrow2"])
 def geom(request):
     e = _forced(request.param)
     yield e
@@ -85,8 +86,9 @@ def check(engine, oracle, R, S, plan, wide_rowids=False):
 @pytest.mark.parametrize("nR,nS,nlow", [(60_000, 200_000, 3),        # 20 K build / 66 K probe per partition: 2 chunks, 5 tasks
                                         (8_960, 8_192, 1), (8_961, 8_193, 1),   # the half-size table / task, and one beyond
                                         (200_000, 50_000, 4),        # build on S (the smaller bucket), pairs stay (rowR,rowS)
-                                        (17_920, 16_384, 1),         # exactly one table, exactly one task
-                                        (17_921, 16_385, 1),         # one tuple beyond each
+                                        (16_352, 16_384, 1),         # exactly one table, exactly one task
+                                        (16_353, 16_385, 1),         # one tuple beyond each
+                                        (17_920, 16_384, 1),         # (the table of rounds 1-2, now kernel 8: two chunks here)
                                         (300_000, 300_000, 1500)])   # 200-tuple partitions through the same kernels
 def test_pkfk_16_bit_plan(big, oracle, nR, nS, nlow):
     pkfk_case(big, oracle, nR, nS, nlow)
@@ -104,6 +106,8 @@ def pkfk_case(eng, oracle, nR, nS, nlow, plan=None):
 @pytest.mark.parametrize("nR,nS,nlow", [(60_000, 200_000, 3),                     # chunks and several tasks per partition
                                         (17_000, 20_480, 1), (8_900, 10_241, 1),   # the 20-slot tasks: exactly one, one beyond
                                         (12_288, 12_288, 1), (12_289, 12_289, 1),  # the 12288-entry geometry: exactly, one beyond
+                                        (16_352, 16_384, 1), (16_353, 16_385, 1),  # the 16352-entry table / 16-slot tasks (kernel 2; 17920 for kernel 8)
+                                        (17_920, 16_000, 1), (17_921, 18_000, 1),
                                         (6_144, 6_144, 1), (6_145, 6_145, 1),      # ... and its half-size form
                                         (200_000, 50_000, 4)])                     # build on S, pairs stay (rowR,rowS)
 def test_pkfk_16_bit_plan_new_geometries(geom, oracle, nR, nS, nlow):

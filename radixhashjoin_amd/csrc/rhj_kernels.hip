@@ -1813,10 +1813,14 @@ k_join_ct(const RelView<NARROW> R, const RelView<NARROW> S, const JoinTask *__re
                     for (int s = 0; s < PT; s++) e[s] = ent[lo[s] + j];      // (past the bucket's end: some other entry, ignored)
 #pragma unroll
                     for (int s = 0; s < PT; s++) {
-                        const u32 xl = (u32)e[s] ^ klo[s], xh = (u32)(e[s] >> 32) ^ khi[s];
-                        if (j < len[s] && xh == 0 && xl < 0x10000u) m[s] |= 0x10000u << j;
+                        // (no `j < len` here: an entry of another bucket has another key; what lies behind the table's end is
+                        // masked off below)
+                        const u32 xl = (u32)e[s] ^ klo[s];
+                        if ((u32)(e[s] >> 32) == khi[s] && xl < 0x10000u) m[s] |= 0x10000u << j;
                     }
                 }
+#pragma unroll
+                for (int s = 0; s < PT; s++) m[s] &= ((1u << len[s]) - 1u) << 16;
             }
 #pragma unroll
             for (int s = 0; s < PT; s++) {

@@ -70,7 +70,7 @@ __device__ __forceinline__ u32 wave_incl_scan(u32 v, int lane)
 
 // Workgroup exclusive scan. wsum: LDS scratch of THREADS/64 words. Ends with a barrier, so wsum
 // may be reused immediately by the caller.
-template <int THREADS>
+template <int THREADS, bool TRAILING_SYNC = true>
 __device__ __forceinline__ u32 block_excl_scan(u32 v, u32 *wsum, u32 &total)
 {
     constexpr int NW = THREADS / 64;
@@ -85,7 +85,7 @@ __device__ __forceinline__ u32 block_excl_scan(u32 v, u32 *wsum, u32 &total)
         if (i < w) base += s;
         tot += s;
     }
-    __syncthreads();
+    if (TRAILING_SYNC) __syncthreads();      // (false: the caller does not touch wsum before its own next barrier)
     total = tot;
     return base + inc - v;
 }
@@ -1634,7 +1634,9 @@ constexpr int CT13_CHUNK = 17920, CT13_BUCKET_BITS = 13;
 // register picture (18 build slots, 16 probe slots, 128 VGPRs) is unchanged.  The kernel's cost per task does not shrink
 // with the partition (every slot row is walked), so the full-size geometry is 2-3x too expensive there (measured at
 // 3 * 10^8: 8.9 ms against 5.1 ms for the chunked 16-byte-entry kernel).
-constexpr int CTH_THREADS = 512, CTH_CHUNK = 8960, CTH_BUCKET_BITS = 12;
+constexpr int CTH_THREADS = 512, CTH_CHUNK = 8160, CTH_BUCKET_BITS = 13;      // (8960 entries in 4096 buckets until round 3: the probe tasks
+// of 8192 tuples bound the partition size anyway, and twice the buckets are worth more than the last 800 entries)
+constexpr int CTHW_CHUNK = 8960, CTHW_BUCKET_BITS = 12;                           // the 20-slot form keeps the larger table
 // ... and with 20 probe slots per thread instead of 16 (narrow format only; 12 spilled VGPRs): partitions whose probe side is
 // just beyond one 16-slot task (2.2 * 10^9 tuples under 17 or 18 bits: 16.8 K / 8.4 K per partition) would otherwise be cut into
 // two tasks that both build the whole table
@@ -1685,11 +1687,14 @@ k_join_ct(const RelView<NARROW> R, const RelView<NARROW> S, const JoinTask *__re
     static_assert(EPT % PT == 0 && EPT <= 32 && NB % (2 * THREADS) == 0 && CHUNK < (int)CT_NONE && BPT % BB == 0 && NW <= 64,
                   "geometry");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    u64 *ent = reinterpret_cast<u64 *>(smem);                                // CHUNK entries {key48 | idx16}, bucket order
-    u64 *rid = ent;                                                          // ... later CHUNK build rowIDs, arrival order
-    u32 *off32 = reinterpret_cast<u32 *>(ent + CHUNK);                       // NB/2 + 2 words of two 16-bit halves
+    // the bucket offsets first: their LDS addresses are then the byte offset itself (behind the table they cost two more
+    // address instructions per access: the base does not fit the 16-bit immediate of a ds instruction)
+    u32 *off32 = reinterpret_cast<u32 *>(smem);                              // NB/2 + 2 words of two 16-bit halves
     const unsigned short *off16 = reinterpret_cast<const unsigned short *>(off32);   // off16[h], h in [0, NB]
-    u32 *wsum = off32 + NB / 2 + 2;                                          // NW scan scratch
+    u64 *ent = reinterpret_cast<u64 *>(off32 + NB / 2 + 2);                  // CHUNK entries {key48 | idx16}, bucket order
+    // ... later the CHUNK build rowIDs in TABLE order (4 bytes each in the narrow format)
+    // (a compare round reads up to CT_MASK_BITS - 1 entries past a bucket's end: behind the table lie >= 128 bytes of scratch)
+    u32 *wsum = reinterpret_cast<u32 *>(ent + CHUNK);                        // NW scan scratch
     u32 *wtot = wsum + NW;                                                   // NW match totals
     u64 *gres = reinterpret_cast<u64 *>(wtot + NW);                          // 1
     u64 *dummy = gres + 1;                                                   // target of the LDS writes of out-of-range slots:
@@ -1702,6 +1707,8 @@ k_join_ct(const RelView<NARROW> R, const RelView<NARROW> S, const JoinTask *__re
     const bool build_is_S = task.build_is_S != 0;
     typedef typename RelView<NARROW>::Rid Rid;
     typedef typename RelView<NARROW>::Both Both;
+    Rid *rid = reinterpret_cast<Rid *>(ent);
+    Rid *rdummy = reinterpret_cast<Rid *>(dummy);
     const RelView<NARROW> B = (build_is_S ? S : R).at(task.bbeg);
     const RelView<NARROW> P = (build_is_S ? R : S).at(task.pbeg);
     const u32 nb = task.blen, np = task.plen;                                // np <= THREADS * EPT (host: probe_split)
@@ -1745,7 +1752,7 @@ k_join_ct(const RelView<NARROW> R, const RelView<NARROW> S, const JoinTask *__re
 #pragma unroll
             for (int j = 0; j < WPT; j++) { wd[j] = off32[tid * WPT + j]; loc += (wd[j] & 0xFFFFu) + (wd[j] >> 16); }
             u32 tot;
-            u32 ex = block_excl_scan<THREADS>(loc, wsum, tot);
+            u32 ex = block_excl_scan<THREADS, false>(loc, wsum, tot);
 #pragma unroll
             for (int j = 0; j < WPT; j++) {
                 const u32 c0 = wd[j] & 0xFFFFu, c1 = wd[j] >> 16;
@@ -1930,47 +1937,81 @@ k_join_ct(const RelView<NARROW> R, const RelView<NARROW> S, const JoinTask *__re
         if (lane == 0) wtot[w] = wave_total;
         __syncthreads();                                                     // every wavefront is done with the table
         stamp();                                                             // 6: barrier passed
+        // the one reservation of the task is on its way to L2 while the rowIDs go into the table
+        const u32 mine = lane < NW ? wtot[lane] : 0u;
+        const u32 inc = wave_incl_scan(mine, lane);
+        const u32 chunk_total = __shfl(inc, NW - 1, 64);
+        const u32 wbase = __shfl(inc - mine, w, 64);
+        u64 reserved = 0;
+        if (tid == 0 && chunk_total) reserved = atomicAdd(out_count, (u64)chunk_total);
         {
             int td = tid0;
             asm volatile("" : "+v"(td));
             const int nvd = nc > (u32)td ? (int)((nc - (u32)td + THREADS - 1) / THREADS) : 0;
 #pragma unroll
             for (int k = 0; k < BPT; k++)
-                *(k < nvd ? &rid[(k & 1) ? (ppos[k >> 1] >> 16) : (ppos[k >> 1] & 0xFFFFu)] : dummy) = brid[k];   // table order
+                *(k < nvd ? &rid[(k & 1) ? (ppos[k >> 1] >> 16) : (ppos[k >> 1] & 0xFFFFu)] : rdummy) = brid[k];   // table order
         }
         stamp();                                                             // 7: rowIDs in LDS
-        const u32 mine = lane < NW ? wtot[lane] : 0u;
-        const u32 inc = wave_incl_scan(mine, lane);
-        const u32 chunk_total = __shfl(inc, NW - 1, 64);
-        const u32 wbase = __shfl(inc - mine, w, 64);
-        if (tid == 0 && chunk_total) *gres = atomicAdd(out_count, (u64)chunk_total);
+        if (tid == 0 && chunk_total) *gres = reserved;
         __syncthreads();
         stamp();                                                             // 8: output reserved
         if (out != nullptr && wave_total) {
             u64 o = *gres + wbase;                                           // next output slot of this wavefront
+            // The first match of every slot: EPT independent LDS reads in flight together (one read, wait, store per slot
+            // left 16 LDS round trips per thread exposed behind one another).
+            Rid br0[EPT];
 #pragma unroll
             for (int k = 0; k < EPT; k++) {
-                const u32 lo = mi[k] & 0xFFFFu;
+                const u32 mk = mi[k] >> 16;
+                br0[k] = rid[(mi[k] & 0xFFFFu) + (mk ? (u32)__ffs((int)mk) - 1u : 0u)];
+            }
+            // Pass 1 stores every slot's first match: ballot + mbcnt compaction, consecutive lanes -> consecutive pairs.  In
+            // the FK case (unique build keys) that is everything.
+            u32 more = 0;
+#pragma unroll
+            for (int k = 0; k < EPT; k++) {
                 u32 mask = mi[k] >> 16;
-                // round r stores the (r+1)-th match of every lane that has one: ballot + mbcnt compaction, consecutive
-                // lanes -> consecutive pairs.  One round in the FK case; no cross-lane scan with duplicates either.
-                for (unsigned long long bal = __ballot(mask != 0); bal != 0; bal = __ballot(mask != 0)) {
-                    if (mask) {
-                        const u64 dst = o + (u64)__popcll(bal & lt);
-                        const u32 bpos = (u32)__ffs((int)mask) - 1;
-                        mask &= mask - 1;
-                        if (dst < out_capacity) {
-                            const u64 br = rid[lo + bpos];
-                            Pair pr;
-                            if (build_is_S) { pr.r = prid[k]; pr.s = br; }      // orderFlag, Result.cpp:64-68
-                            else            { pr.r = br; pr.s = prid[k]; }
-                            // plain (not nontemporal) stores: a wavefront's pair run continues in the next slot's store a
-                            // microsecond later; with the nt hint the shared 128 B line at the seam went to HBM twice
-                            // ([measured] WRITE_SIZE 18.32 GB per 10^9 pairs against 16.03, same kernel time within 1 %)
-                            out[dst] = pr;
-                        }
+                const unsigned long long bal = __ballot(mask != 0);
+                if (mask) {
+                    const u64 dst = o + (u64)__popcll(bal & lt);
+                    mask &= mask - 1;
+                    if (dst < out_capacity) {
+                        Pair pr;
+                        if (build_is_S) { pr.r = prid[k]; pr.s = br0[k]; }     // orderFlag, Result.cpp:64-68
+                        else            { pr.r = br0[k]; pr.s = prid[k]; }
+                        // plain (not nontemporal) stores: a wavefront's pair run continues in the next slot's store a
+                        // microsecond later; with the nt hint the shared 128 B line at the seam went to HBM twice
+                        // ([measured] WRITE_SIZE 18.32 GB per 10^9 pairs against 16.03, same kernel time within 1 %)
+                        out[dst] = pr;
                     }
-                    o += (u64)__popcll(bal);
+                    mi[k] = (mi[k] & 0xFFFFu) | (mask << 16);
+                    more |= mask;
+                }
+                o += (u64)__popcll(bal);
+            }
+            // Pass 2: further matches of a slot (duplicates on the build side), behind the first matches of the wavefront --
+            // the order of the pairs is free.  Round r stores the (r+2)-th match of every lane that has one.
+            if (__ballot(more != 0) != 0) {
+#pragma unroll
+                for (int k = 0; k < EPT; k++) {
+                    const u32 lo = mi[k] & 0xFFFFu;
+                    u32 mask = mi[k] >> 16;
+                    for (unsigned long long bal = __ballot(mask != 0); bal != 0; bal = __ballot(mask != 0)) {
+                        if (mask) {
+                            const u64 dst = o + (u64)__popcll(bal & lt);
+                            const u32 bpos = (u32)__ffs((int)mask) - 1;
+                            mask &= mask - 1;
+                            if (dst < out_capacity) {
+                                const u64 br = rid[lo + bpos];
+                                Pair pr;
+                                if (build_is_S) { pr.r = prid[k]; pr.s = br; }
+                                else            { pr.r = br; pr.s = prid[k]; }
+                                out[dst] = pr;
+                            }
+                        }
+                        o += (u64)__popcll(bal);
+                    }
                 }
             }
         }
@@ -2089,7 +2130,7 @@ u32 join_probe_split(int kind)
 }
 u32 join_table_tuples(int kind)
 {
-    return kind == JK_CT ? (u32)CT_CHUNK : kind == JK_CT_13 || kind == JK_CT_WIDE ? (u32)CT13_CHUNK : kind == JK_CT_HALF || kind == JK_CT_HALF_WIDE ? (u32)CTH_CHUNK :
+    return kind == JK_CT ? (u32)CT_CHUNK : kind == JK_CT_13 || kind == JK_CT_WIDE ? (u32)CT13_CHUNK : kind == JK_CT_HALF ? (u32)CTH_CHUNK : kind == JK_CT_HALF_WIDE ? (u32)CTHW_CHUNK :
            kind == JK_CT_MID ? (u32)CTM_CHUNK : kind == JK_CT_HALF_MID ? (u32)CTHM_CHUNK : kind == JK_BKT_BIG ? (u32)BJ2_CHUNK : (u32)BJ_CHUNK;
 }
 int join_ct_min_radix_bits() { return CT_MIN_RADIX_BITS; }
@@ -2111,7 +2152,7 @@ static int current_device_slot()
 
 static size_t ct_lds_bytes(int threads = CT_THREADS, int chunk = CT_CHUNK, int bbits = CT_BUCKET_BITS)
 {
-    return (size_t)chunk * 8 + ((size_t)(1 << bbits) / 2 + 2 + 2 * (threads / 64)) * 4 + 24;
+    return (size_t)chunk * 8 + ((size_t)(1 << bbits) / 2 + 2 + 2 * (threads / 64)) * 4 + 24 + (threads < 1024 ? 64 : 0);   // (>= 128 B behind the table)
 }
 
 // hipFuncSetAttribute results are kept: a refused LDS size would otherwise surface later as an anonymous launch failure.
@@ -2161,7 +2202,7 @@ static void allow_big_lds()
     SET_LDS((k_join_ct<CT_THREADS, CTM_CHUNK, CTM_BUCKET_BITS, CTM_EPT, false, false>), ct_lds_bytes(CT_THREADS, CTM_CHUNK, CTM_BUCKET_BITS));
     SET_LDS((k_join_ct<CTH_THREADS, CTHM_CHUNK, CTHM_BUCKET_BITS, CTM_EPT, false, true>), ct_lds_bytes(CTH_THREADS, CTHM_CHUNK, CTHM_BUCKET_BITS));
     SET_LDS((k_join_ct<CTH_THREADS, CTHM_CHUNK, CTHM_BUCKET_BITS, CTM_EPT, false, false>), ct_lds_bytes(CTH_THREADS, CTHM_CHUNK, CTHM_BUCKET_BITS));
-    SET_LDS((k_join_ct<CTH_THREADS, CTH_CHUNK, CTH_BUCKET_BITS, CT_EPT_WIDE, false, true>), ct_lds_bytes(CTH_THREADS, CTH_CHUNK, CTH_BUCKET_BITS));
+    SET_LDS((k_join_ct<CTH_THREADS, CTHW_CHUNK, CTHW_BUCKET_BITS, CT_EPT_WIDE, false, true>), ct_lds_bytes(CTH_THREADS, CTHW_CHUNK, CTHW_BUCKET_BITS));
     SET_LDS((k_join_bkt<BJ_THREADS, BJ_CHUNK, BJ_BUCKET_BITS, BJ_EPT, false, true, true>), bj_lds_bytes(BJ_THREADS, BJ_CHUNK, BJ_BUCKET_BITS));
     SET_LDS(k_scatter_wc_n<WC_THREADS>, wc_lds_bytes(WC_MAX_BITS, WC_THREADS));
     SET_LDS(k_scatter_wc_n<WC_THREADS_SMALL>, wc_lds_bytes(WC_MAX_BITS, WC_THREADS_SMALL));
@@ -2465,7 +2506,7 @@ void launch_join(hipStream_t st, const void *d_R, const u64 *d_startR, const voi
         const bool tg = d_tag_base != nullptr;                              // sender tags: the one-table kernel only (the host sees to it)
         if (kind == JK_BKT) { if (tg) LAUNCH_BKT_N(true); else LAUNCH_BKT_N(false); }
         else if (kind == JK_CT_HALF) LAUNCH_CT_N(CTH_THREADS, CTH_CHUNK, CTH_BUCKET_BITS, CT_EPT);
-        else if (kind == JK_CT_HALF_WIDE) LAUNCH_CT_N(CTH_THREADS, CTH_CHUNK, CTH_BUCKET_BITS, CT_EPT_WIDE);
+        else if (kind == JK_CT_HALF_WIDE) LAUNCH_CT_N(CTH_THREADS, CTHW_CHUNK, CTHW_BUCKET_BITS, CT_EPT_WIDE);
         else if (kind == JK_CT_WIDE) LAUNCH_CT_N(CT_THREADS, CT13_CHUNK, CT13_BUCKET_BITS, CT_EPT_WIDE);
         else if (kind == JK_CT_13) LAUNCH_CT_N(CT_THREADS, CT13_CHUNK, CT13_BUCKET_BITS, CT_EPT);
         else if (kind == JK_CT_MID) LAUNCH_CT_N(CT_THREADS, CTM_CHUNK, CTM_BUCKET_BITS, CTM_EPT);

@@ -84,7 +84,7 @@ def check(engine, oracle, R, S, plan, wide_rowids=False):
 
 
 @pytest.mark.parametrize("nR,nS,nlow", [(60_000, 200_000, 3),        # 20 K build / 66 K probe per partition: 2 chunks, 5 tasks
-                                        (8_960, 8_192, 1), (8_961, 8_193, 1),   # the half-size table / task, and one beyond
+                                        (8_160, 8_192, 1), (8_161, 8_193, 1), (8_960, 8_000, 1),   # the half-size table / task, one beyond (8960: its 20-slot form)
                                         (200_000, 50_000, 4),        # build on S (the smaller bucket), pairs stay (rowR,rowS)
                                         (16_352, 16_384, 1),         # exactly one table, exactly one task
                                         (16_353, 16_385, 1),         # one tuple beyond each

@@ -679,7 +679,11 @@ int partition_relation(rhj_ctx *ctx, const void *d_in, u64 n, int passes, int b1
 int choose_join_kind(const rhj_ctx *ctx, u64 nR, u64 nS, u64 nparts, int radix_bits, bool narrow = false)
 {
     const u64 nbuild = nR < nS ? nR : nS;
-    if (!(ctx->opt_big_tables == 1 || (ctx->opt_big_tables < 0 && nbuild / nparts > (u64)BJ_CHUNK))) return JK_BKT;
+    // ... and from half a table on when the plan allows the compact-table kernel: its 6144-entry geometry with row guards
+    // handles a tuple in two thirds of the one-table kernel's time ([measured] 1.5 - 2.7 * 10^8 tuples under 16 bits)
+    const bool ct_ok = radix_bits >= join_ct_min_radix_bits() && ctx->opt_big_kernel != JK_BKT_BIG;
+    const u64 big_from = ct_ok ? (u64)CT_GUARDED_FROM : (u64)BJ_CHUNK;
+    if (!(ctx->opt_big_tables == 1 || (ctx->opt_big_tables < 0 && nbuild / nparts > big_from))) return JK_BKT;
     if (radix_bits < join_ct_min_radix_bits() || ctx->opt_big_kernel == JK_BKT_BIG) return JK_BKT_BIG;
     if (jk_is_ct(ctx->opt_big_kernel) && !jk_ct_narrow_only(ctx->opt_big_kernel)) return ctx->opt_big_kernel;
     if (ctx->opt_big_kernel == JK_CT_WIDE) return narrow ? JK_CT_WIDE : JK_CT_13;
@@ -688,7 +692,8 @@ int choose_join_kind(const rhj_ctx *ctx, u64 nR, u64 nS, u64 nparts, int radix_b
     // AND its 8192-tuple probe tasks (a partition cut into two tasks builds its table twice)
     const u64 nprobe = nR < nS ? nS : nR, ab = nbuild / nparts, ap = nprobe / nparts;
     auto fits = [&](int k) { return ab <= (u64)join_table_tuples(k) * 15 / 16 && ap <= (u64)join_probe_split(k) * 15 / 16; };
-    if (fits(JK_CT_HALF_MID)) return JK_CT_HALF_MID; // 12 + 12 slot rows, 6144 entries: partitions of up to 5.76 K tuples
+    // 12 + 12 slot rows, 6144 entries: partitions of up to 5.76 K tuples; with row guards while two or more rows stay empty
+    if (fits(JK_CT_HALF_MID)) return ab <= (u64)CT_GUARDED_UPTO && ap <= (u64)CT_GUARDED_UPTO ? JK_CT_HALF_MID_G : JK_CT_HALF_MID;
     if (fits(JK_CT_HALF)) return JK_CT_HALF;
     // 20 probe slots per thread (narrow partitions only) before a partition's probe side is cut into two tasks that build the
     // table twice: [measured] 2.2 * 10^9 x 2.2 * 10^9, join kernel 32.5 ms with two 16-slot tasks per partition

@@ -24,6 +24,9 @@ constexpr int BJ_BUCKET_BITS = 11;                // 2048 hash buckets (offsets:
 constexpr int BJ_EPT = 8;                         // probe tuples per thread per tile
 constexpr int BJ_TILE = BJ_THREADS * BJ_EPT;      // 4096
 constexpr int BJ_FIT = BJ_CHUNK * 15 / 16;        // plan: average build partition <= 3960 tuples
+// under a plan of >= 16 bits, average build partitions of CT_GUARDED_FROM ... CT_GUARDED_UPTO tuples go to the compact-table
+// kernel's 6144-entry geometry with row guards (k_join_ct<.., GUARD>): 4 ... 10 of its 12 slot rows in use
+constexpr int CT_GUARDED_FROM = 2048, CT_GUARDED_UPTO = 5120;
 // small joins run unpartitioned in one launch (k_join_bkt DIRECT): every 4096-tuple probe tile re-builds the table chunks
 constexpr u64 DIRECT_MAX_BUILD = 12ull * BJ_CHUNK; // build side of at most 12 table chunks ...
 constexpr u64 DIRECT_MAX_PROBE = 131072;          // ... probed by at most 32 workgroups
@@ -95,7 +98,7 @@ bool fused_two_pass_ok(int b1, int b2);
 // chunks, probe side re-read per chunk (any radix plan); JK_CT compact 8-byte entries, both sides read once
 // (plans that remove >= 16 payload bits)
 enum JoinKernel { JK_BKT = 0, JK_BKT_BIG = 1, JK_CT = 2, JK_CT_HALF = 3, JK_CT_WIDE = 4, JK_CT_HALF_WIDE = 5, JK_CT_MID = 6, JK_CT_HALF_MID = 7, JK_CT_13 = 8,
-                  JK_LAST = JK_CT_13 };
+                  JK_CT_HALF_MID_G = 9, JK_LAST = JK_CT_HALF_MID_G };
 inline bool jk_is_ct(int k) { return k >= JK_CT && k <= JK_LAST; }                           // a compact-table geometry (48-bit keys: needs >= 16 radix bits)
 inline bool jk_ct_narrow_only(int k) { return k == JK_CT_WIDE || k == JK_CT_HALF_WIDE; }    // 20 probe slots: {payload, rowID} partitions only
 // _WIDE: 20 probe slots per thread (narrow format only); _MID: a 12288-entry table and 12 slots per thread (partitions of 8.4 - 11.5 K);

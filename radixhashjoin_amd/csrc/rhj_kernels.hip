@@ -1665,7 +1665,7 @@ constexpr int CT_NSTAMP = 16;
 
 // skip (optional): a device word that is non-zero when this join is going to be repeated in another format (a rowID did
 // not fit the narrow format): nothing to do then.
-template <int THREADS, int CHUNK, int BBITS, int EPT, bool STAMPS, bool NARROW>
+template <int THREADS, int CHUNK, int BBITS, int EPT, bool STAMPS, bool NARROW, bool GUARD = false>
 __global__ void __launch_bounds__(THREADS, THREADS * (CHUNK <= 8960 ? 2 : 1) / 256)   // wavefronts per SIMD: 2 (256 registers per lane) or 4 (128)
 k_join_ct(const RelView<NARROW> R, const RelView<NARROW> S, const JoinTask *__restrict__ tasks,
           const u32 *__restrict__ ntasks, int radix_bits, Pair *__restrict__ out, u64 out_capacity,
@@ -1719,6 +1719,13 @@ k_join_ct(const RelView<NARROW> R, const RelView<NARROW> S, const JoinTask *__re
     const int nv = np > (u32)tid ? (int)((np - (u32)tid + THREADS - 1) / THREADS) : 0;
 
     const int tid0 = tid, nv0 = nv;
+    // Slot row k holds tuples [k * THREADS, (k + 1) * THREADS) of the chunk / task: whether a row is in use is the same for
+    // every thread (a scalar compare and branch).  GUARD: rows beyond the partition are skipped, so a partition that fills
+    // half the rows pays for half of them and one geometry serves a range of partition sizes at a cost that follows the
+    // partition ([measured] 6144-entry geometry, 2 * 10^8 tuples, 3 K-tuple partitions: join kernel 2.04 ms against 2.83
+    // unguarded and 2.58 for k_join_bkt).  The branches cost full partitions 10 % (they end the batches of loads and LDS
+    // operations: 10^9 tuples 9.1 -> 10.2 ms), so kernels for full tables are instantiated without them.
+#define USED(k, n) (!GUARD || (u32)(k) * (u32)THREADS < (n))
     for (u32 cb = 0; cb < nb; cb += CHUNK) {
         const u32 nc = (nb - cb < (u32)CHUNK) ? nb - cb : (u32)CHUNK;
         // Addresses and range predicates of the 18 build and 16 probe slots depend only on the thread index: left
@@ -1737,9 +1744,14 @@ k_join_ct(const RelView<NARROW> R, const RelView<NARROW> S, const JoinTask *__re
         for (int k0 = 0; k0 < BPT; k0 += BB) {
             u64 bt[BB];
 #pragma unroll
-            for (int k = k0; k < k0 + BB; k++) bt[k - k0] = B.payload(cb + (k < nvb ? (u32)k * THREADS + tid : 0u));
+            for (int k = k0; k < k0 + BB; k++) {
+                bt[k - k0] = 0;
+                if (USED(k, nc)) bt[k - k0] = B.payload(cb + (k < nvb ? (u32)k * THREADS + tid : 0u));
+            }
 #pragma unroll
             for (int k = k0; k < k0 + BB; k++) {
+                kr[k] = 0;
+                if (!USED(k, nc)) continue;
                 const u64 key = bt[k - k0] >> rb;
                 const u32 h = k < nvb ? ct_bucket<BBITS>(key) : (u32)NB + 2u, sh = (h & 1u) * 16u;   // NB + 2: a padding word
                 kr[k] = (key << 16) | ((atomicAdd(&off32[h >> 1], 1u << sh) >> sh) & 0xFFFFu);
@@ -1769,6 +1781,7 @@ k_join_ct(const RelView<NARROW> R, const RelView<NARROW> S, const JoinTask *__re
             const int nvp = nc > (u32)tp ? (int)((nc - (u32)tp + THREADS - 1) / THREADS) : 0;
 #pragma unroll
             for (int k = 0; k < BPT; k++) {
+                if (!USED(k, nc)) { if (!(k & 1)) ppos[k >> 1] = 0; continue; }
                 const u64 key = kr[k] >> 16;
                 const u32 pos = off16[ct_bucket<BBITS>(key)] + ((u32)kr[k] & 0xFFFFu);
                 *(k < nvp ? &ent[pos] : dummy) = (key << 16) | (u64)((u32)k * THREADS + tp);
@@ -1787,13 +1800,20 @@ k_join_ct(const RelView<NARROW> R, const RelView<NARROW> S, const JoinTask *__re
         Both ring[DEPTH][PT];
         asm volatile("" : "+v"(tid), "+v"(nv));
 #pragma unroll
-        for (int t = 0; t < DEPTH && t < NT; t++)
+        for (int t = 0; t < DEPTH && t < NT; t++) {
+            if (!USED(t * PT, np)) continue;
 #pragma unroll
             for (int s = 0; s < PT; s++) ring[t][s] = P.both(t * PT + s < nv ? (u32)(t * PT + s) * THREADS + tid : 0u);
+        }
 #pragma unroll
         for (int t = 0; t < NT; t++) {
             u32 khi[PT], klo[PT];                                            // key << 16, to compare with an entry's upper 48 bits
             u32 lo[PT], len[PT], m[PT], maxlen = 0;
+            if (!USED(t * PT, np)) {                                         // the task ends before this tile (same for every thread)
+#pragma unroll
+                for (int s = 0; s < PT; s++) { prid[t * PT + s] = 0; mi[t * PT + s] = 0; }
+                continue;
+            }
 #pragma unroll
             for (int s = 0; s < PT; s++) {
                 const int k = t * PT + s;
@@ -1805,7 +1825,7 @@ k_join_ct(const RelView<NARROW> R, const RelView<NARROW> S, const JoinTask *__re
                 len[s] = k < nv ? off16[h + 1] - lo[s] : 0u;
                 maxlen = len[s] > maxlen ? len[s] : maxlen;
             }
-            if (t + DEPTH < NT) {                                            // the slot is free: next tile on its way
+            if (t + DEPTH < NT && USED((t + DEPTH) * PT, np)) {               // the slot is free: next tile on its way
 #pragma unroll
                 for (int s = 0; s < PT; s++)
                     ring[t % DEPTH][s] = P.both((t + DEPTH) * PT + s < nv ? (u32)((t + DEPTH) * PT + s) * THREADS + tid : 0u);
@@ -1931,7 +1951,10 @@ k_join_ct(const RelView<NARROW> R, const RelView<NARROW> S, const JoinTask *__re
             asm volatile("" : "+v"(tq));
             const int nvq = nc > (u32)tq ? (int)((nc - (u32)tq + THREADS - 1) / THREADS) : 0;
 #pragma unroll
-            for (int k = 0; k < BPT; k++) brid[k] = B.rowid(cb + (k < nvq ? (u32)k * THREADS + tq : 0u));
+            for (int k = 0; k < BPT; k++) {
+                brid[k] = 0;
+                if (USED(k, nc)) brid[k] = B.rowid(cb + (k < nvq ? (u32)k * THREADS + tq : 0u));
+            }
         }
         stamp();                                                             // 5: rowID loads issued
         if (lane == 0) wtot[w] = wave_total;
@@ -1950,7 +1973,8 @@ k_join_ct(const RelView<NARROW> R, const RelView<NARROW> S, const JoinTask *__re
             const int nvd = nc > (u32)td ? (int)((nc - (u32)td + THREADS - 1) / THREADS) : 0;
 #pragma unroll
             for (int k = 0; k < BPT; k++)
-                *(k < nvd ? &rid[(k & 1) ? (ppos[k >> 1] >> 16) : (ppos[k >> 1] & 0xFFFFu)] : rdummy) = brid[k];   // table order
+                if (USED(k, nc))
+                    *(k < nvd ? &rid[(k & 1) ? (ppos[k >> 1] >> 16) : (ppos[k >> 1] & 0xFFFFu)] : rdummy) = brid[k];   // table order
         }
         stamp();                                                             // 7: rowIDs in LDS
         if (tid == 0 && chunk_total) *gres = reserved;
@@ -1964,13 +1988,15 @@ k_join_ct(const RelView<NARROW> R, const RelView<NARROW> S, const JoinTask *__re
 #pragma unroll
             for (int k = 0; k < EPT; k++) {
                 const u32 mk = mi[k] >> 16;
-                br0[k] = rid[(mi[k] & 0xFFFFu) + (mk ? (u32)__ffs((int)mk) - 1u : 0u)];
+                br0[k] = 0;
+                if (USED(k, np)) br0[k] = rid[(mi[k] & 0xFFFFu) + (mk ? (u32)__ffs((int)mk) - 1u : 0u)];
             }
             // Pass 1 stores every slot's first match: ballot + mbcnt compaction, consecutive lanes -> consecutive pairs.  In
             // the FK case (unique build keys) that is everything.
             u32 more = 0;
 #pragma unroll
             for (int k = 0; k < EPT; k++) {
+                if (!USED(k, np)) continue;
                 u32 mask = mi[k] >> 16;
                 const unsigned long long bal = __ballot(mask != 0);
                 if (mask) {
@@ -1995,6 +2021,7 @@ k_join_ct(const RelView<NARROW> R, const RelView<NARROW> S, const JoinTask *__re
             if (__ballot(more != 0) != 0) {
 #pragma unroll
                 for (int k = 0; k < EPT; k++) {
+                    if (!USED(k, np)) continue;
                     const u32 lo = mi[k] & 0xFFFFu;
                     u32 mask = mi[k] >> 16;
                     for (unsigned long long bal = __ballot(mask != 0); bal != 0; bal = __ballot(mask != 0)) {
@@ -2018,6 +2045,7 @@ k_join_ct(const RelView<NARROW> R, const RelView<NARROW> S, const JoinTask *__re
         stamp();                                                             // 9: this wavefront's pairs stored (issued)
         if (cb + CHUNK < nb) __syncthreads();                                // the next chunk rebuilds the table over rid
     }
+#undef USED
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -2126,12 +2154,12 @@ u32 join_probe_split(int kind)
 {
     return kind == JK_CT || kind == JK_CT_13 ? (u32)(CT_THREADS * CT_EPT) : kind == JK_CT_HALF ? (u32)(CTH_THREADS * CT_EPT) :
            kind == JK_CT_WIDE ? (u32)(CT_THREADS * CT_EPT_WIDE) : kind == JK_CT_HALF_WIDE ? (u32)(CTH_THREADS * CT_EPT_WIDE) :
-           kind == JK_CT_MID ? (u32)(CT_THREADS * CTM_EPT) : kind == JK_CT_HALF_MID ? (u32)(CTH_THREADS * CTM_EPT) : 0u;
+           kind == JK_CT_MID ? (u32)(CT_THREADS * CTM_EPT) : kind == JK_CT_HALF_MID || kind == JK_CT_HALF_MID_G ? (u32)(CTH_THREADS * CTM_EPT) : 0u;
 }
 u32 join_table_tuples(int kind)
 {
     return kind == JK_CT ? (u32)CT_CHUNK : kind == JK_CT_13 || kind == JK_CT_WIDE ? (u32)CT13_CHUNK : kind == JK_CT_HALF ? (u32)CTH_CHUNK : kind == JK_CT_HALF_WIDE ? (u32)CTHW_CHUNK :
-           kind == JK_CT_MID ? (u32)CTM_CHUNK : kind == JK_CT_HALF_MID ? (u32)CTHM_CHUNK : kind == JK_BKT_BIG ? (u32)BJ2_CHUNK : (u32)BJ_CHUNK;
+           kind == JK_CT_MID ? (u32)CTM_CHUNK : kind == JK_CT_HALF_MID || kind == JK_CT_HALF_MID_G ? (u32)CTHM_CHUNK : kind == JK_BKT_BIG ? (u32)BJ2_CHUNK : (u32)BJ_CHUNK;
 }
 int join_ct_min_radix_bits() { return CT_MIN_RADIX_BITS; }
 
@@ -2202,6 +2230,8 @@ static void allow_big_lds()
     SET_LDS((k_join_ct<CT_THREADS, CTM_CHUNK, CTM_BUCKET_BITS, CTM_EPT, false, false>), ct_lds_bytes(CT_THREADS, CTM_CHUNK, CTM_BUCKET_BITS));
     SET_LDS((k_join_ct<CTH_THREADS, CTHM_CHUNK, CTHM_BUCKET_BITS, CTM_EPT, false, true>), ct_lds_bytes(CTH_THREADS, CTHM_CHUNK, CTHM_BUCKET_BITS));
     SET_LDS((k_join_ct<CTH_THREADS, CTHM_CHUNK, CTHM_BUCKET_BITS, CTM_EPT, false, false>), ct_lds_bytes(CTH_THREADS, CTHM_CHUNK, CTHM_BUCKET_BITS));
+    SET_LDS((k_join_ct<CTH_THREADS, CTHM_CHUNK, CTHM_BUCKET_BITS, CTM_EPT, false, true, true>), ct_lds_bytes(CTH_THREADS, CTHM_CHUNK, CTHM_BUCKET_BITS));
+    SET_LDS((k_join_ct<CTH_THREADS, CTHM_CHUNK, CTHM_BUCKET_BITS, CTM_EPT, false, false, true>), ct_lds_bytes(CTH_THREADS, CTHM_CHUNK, CTHM_BUCKET_BITS));
     SET_LDS((k_join_ct<CTH_THREADS, CTHW_CHUNK, CTHW_BUCKET_BITS, CT_EPT_WIDE, false, true>), ct_lds_bytes(CTH_THREADS, CTHW_CHUNK, CTHW_BUCKET_BITS));
     SET_LDS((k_join_bkt<BJ_THREADS, BJ_CHUNK, BJ_BUCKET_BITS, BJ_EPT, false, true, true>), bj_lds_bytes(BJ_THREADS, BJ_CHUNK, BJ_BUCKET_BITS));
     SET_LDS(k_scatter_wc_n<WC_THREADS>, wc_lds_bytes(WC_MAX_BITS, WC_THREADS));
@@ -2511,6 +2541,10 @@ void launch_join(hipStream_t st, const void *d_R, const u64 *d_startR, const voi
         else if (kind == JK_CT_13) LAUNCH_CT_N(CT_THREADS, CT13_CHUNK, CT13_BUCKET_BITS, CT_EPT);
         else if (kind == JK_CT_MID) LAUNCH_CT_N(CT_THREADS, CTM_CHUNK, CTM_BUCKET_BITS, CTM_EPT);
         else if (kind == JK_CT_HALF_MID) LAUNCH_CT_N(CTH_THREADS, CTHM_CHUNK, CTHM_BUCKET_BITS, CTM_EPT);
+        else if (kind == JK_CT_HALF_MID_G)
+            hipLaunchKernelGGL((k_join_ct<CTH_THREADS, CTHM_CHUNK, CTHM_BUCKET_BITS, CTM_EPT, false, true, true>), dim3(grid), dim3(CTH_THREADS),
+                               ct_lds_bytes(CTH_THREADS, CTHM_CHUNK, CTHM_BUCKET_BITS), st, nR, nS, d_tasks, d_ntasks, radix_bits, o, out_capacity,
+                               d_out_count, (u64 *)nullptr, 0u, d_skip);
         else LAUNCH_CT_N(CT_THREADS, CT_CHUNK, CT_BUCKET_BITS, CT_EPT);     // JK_CT (the host never asks for another kind here)
 #undef LAUNCH_BKT_N
 #undef LAUNCH_CT_N
@@ -2530,6 +2564,12 @@ void launch_join(hipStream_t st, const void *d_R, const u64 *d_startR, const voi
     }
     if (kind == JK_CT_HALF_MID) {
         hipLaunchKernelGGL((k_join_ct<CTH_THREADS, CTHM_CHUNK, CTHM_BUCKET_BITS, CTM_EPT, false, false>), dim3(grid), dim3(CTH_THREADS),
+                           ct_lds_bytes(CTH_THREADS, CTHM_CHUNK, CTHM_BUCKET_BITS), st, vR, vS, d_tasks,
+                           d_ntasks, radix_bits, (Pair *)d_out, out_capacity, d_out_count, (u64 *)nullptr, 0u, (const u32 *)nullptr);
+        return;
+    }
+    if (kind == JK_CT_HALF_MID_G) {
+        hipLaunchKernelGGL((k_join_ct<CTH_THREADS, CTHM_CHUNK, CTHM_BUCKET_BITS, CTM_EPT, false, false, true>), dim3(grid), dim3(CTH_THREADS),
                            ct_lds_bytes(CTH_THREADS, CTHM_CHUNK, CTHM_BUCKET_BITS), st, vR, vS, d_tasks,
                            d_ntasks, radix_bits, (Pair *)d_out, out_capacity, d_out_count, (u64 *)nullptr, 0u, (const u32 *)nullptr);
         return;

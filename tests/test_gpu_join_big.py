@@ -18,7 +18,7 @@ from radixhashjoin_amd import Engine, Opts
 from radixhashjoin_amd.binding import GEN_CONST, GEN_R, GEN_S_UNIFORM, GEN_S_ZIPF
 
 pytestmark = pytest.mark.gpu
-BKT_BIG, CT, CT_HALF, CT_WIDE, CT_HALF_WIDE, CT_MID, CT_HALF_MID, CT_13 = 1, 2, 3, 4, 5, 6, 7, 8
+BKT_BIG, CT, CT_HALF, CT_WIDE, CT_HALF_WIDE, CT_MID, CT_HALF_MID, CT_13, CT_HALF_MID_G = 1, 2, 3, 4, 5, 6, 7, 8, 9
 
 
 def _forced(param):
@@ -41,10 +41,10 @@ def big(request):
 
 # the geometries added in round 3 (same kernel template, other table size / slot rows): a shorter list of cases, chosen at
 # their table and task boundaries, plus duplicates, long buckets and the 17-18-bit plans
-@pytest.fixture(scope="module", params=[(CT_WIDE, 2), (CT_HALF_WIDE, 2), (CT_MID, 0), (CT_MID, 2), (CT_HALF_MID, 2), (CT_13, 0), (CT_13, 2)],
+@pytest.fixture(scope="module", params=[(CT_WIDE, 2), (CT_HALF_WIDE, 2), (CT_MID, 0), (CT_MID, 2), (CT_HALF_MID, 2), (CT_13, 0), (CT_13, 2), (CT_HALF_MID_G, 0), (CT_HALF_MID_G, 2)],
                 ids=["compact_table_20slots_narrow2", "compact_table_half_20slots_narrow2", "compact_table_mid",
                      "compact_table_mid_narrow2", "compact_table_half_mid_narrow2", "compact_table_8192_buckets",
-                     "compact_table_8192_buckets_narrow2"])
+                     "compact_table_8192_buckets_narrow2", "compact_table_half_mid_row_guards", "compact_table_half_mid_row_guards_narrow2"])
 def geom(request):
     e = _forced(request.param)
     yield e
@@ -109,6 +109,7 @@ def pkfk_case(eng, oracle, nR, nS, nlow, plan=None):
                                         (16_352, 16_384, 1), (16_353, 16_385, 1),  # the 16352-entry table / 16-slot tasks (kernel 2; 17920 for kernel 8)
                                         (17_920, 16_000, 1), (17_921, 18_000, 1),
                                         (6_144, 6_144, 1), (6_145, 6_145, 1),      # ... and its half-size form
+                                        (1_100, 1_537, 1), (2_048, 2_049, 1), (3_000, 1_100, 1), (1_030, 5_000, 1),   # ... with rows left empty (the row guards)
                                         (200_000, 50_000, 4)])                     # build on S, pairs stay (rowR,rowS)
 def test_pkfk_16_bit_plan_new_geometries(geom, oracle, nR, nS, nlow):
     pkfk_case(geom, oracle, nR, nS, nlow)

@@ -20,6 +20,7 @@ ap.add_argument("--step", type=float, default=1.4)
 ap.add_argument("--reps", type=int, default=3)
 ap.add_argument("--dist", default="uniform")
 ap.add_argument("--sizes", default="")
+ap.add_argument("--big", type=int, default=-1, help="force join.big_tables=1 and this join.big_kernel")
 a = ap.parse_args()
 sizes = [int(x) for x in a.sizes.split(",")] if a.sizes else []
 n = a.lo
@@ -27,6 +28,9 @@ while not a.sizes and n <= a.hi:
     sizes.append(int(n))
     n *= a.step
 e = rhj.Engine(0)
+if a.big >= 0:
+    e.set_option("join.big_tables", 1)
+    e.set_option("join.big_kernel", a.big)
 cap = max(sizes)
 dR, dS, dO = e.alloc(16 * cap), e.alloc(16 * cap), e.alloc(16 * (cap + 1024))
 for n in sizes:

@@ -11,8 +11,8 @@
 // k_join_bkt             JoinJob::run, join_buckets,  JobScheduler.cpp:186-192,
 //                        add_result / addAll          Result.cpp:43-76, 21-35      HBM read+write (16 B/tuple + 16 B/pair)
 //                        (partitions that fit one 16 B/entry LDS table; DIRECT: small unpartitioned joins, no task list)
-// k_join_ct              the same for partitions of up to 17920 build tuples under plans that remove >= 16 payload
-//                        bits: 8 B entries, both sides read once                           HBM + LDS latency
+// k_join_ct              the same for partitions of 2 K ... 17.9 K build tuples under plans that remove >= 16 payload
+//                        bits: 8 B entries, both sides read once; six table geometries         vector ALU + LDS latency
 // k_*2                   the one-pass kernels with grid.y = relation: R and S of a join through the same launches
 // k_scatter_wcn          the same scatter writing the narrow {payload 8 B, rowID 4 B} format inside a join: 32-tuple carry lines for
 //                        <= 8-bit passes, 16-tuple lines for 9-bit passes (17-18-bit plans)                HBM read+write (28 / 24 B/tuple)
@@ -71,10 +71,12 @@ __device__ __forceinline__ u32 wave_incl_scan(u32 v, int lane)
 // Workgroup exclusive scan. wsum: LDS scratch of THREADS/64 words. Ends with a barrier, so wsum
 // may be reused immediately by the caller.
 template <int THREADS, bool TRAILING_SYNC = true>
-__device__ __forceinline__ u32 block_excl_scan(u32 v, u32 *wsum, u32 &total)
+__device__ __forceinline__ u32 block_excl_scan(u32 v, u32 *wsum, u32 &total, int tid = (int)threadIdx.x)
 {
+    // (tid: a caller inside a long loop passes an opaque copy of the thread index, so that &wsum[w] is recomputed here
+    // instead of being hoisted out of the loop and spilled)
     constexpr int NW = THREADS / 64;
-    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int lane = tid & 63, w = tid >> 6;
     const u32 inc = wave_incl_scan(v, lane);
     if (lane == 63) wsum[w] = inc;
     __syncthreads();
@@ -1602,10 +1604,13 @@ k_join_bkt(const RelView<NARROW> R, const RelView<NARROW> S, const JoinTask *__r
 // addAll), organised so that BOTH sides are read from HBM exactly once and every tuple is inserted / probed once:
 //
 //   * inside a partition all payloads share their low radix_bits bits, so (payload >> radix_bits) < 2^48 decides
-//     equality: a table entry is 8 bytes, {48-bit key | 16-bit arrival index of the build tuple}.  17920 entries +
-//     8192 bucket offsets fill the 160 KiB LDS of one workgroup per CU: the whole 15.3 K-tuple build side is ONE
+//     equality: a table entry is 8 bytes, {48-bit key | 16-bit arrival index of the build tuple}.  16352 entries +
+//     16384 bucket offsets fill the 160 KiB LDS of one workgroup per CU: the whole 15.3 K-tuple build side is ONE
 //     table (k_join_bkt needs two 8448-tuple chunks and re-reads the probe side per chunk: 64 GB moved for 48 GB
-//     algorithmic, 2.0 TB/s, round 1).
+//     algorithmic, 2.0 TB/s, round 1).  The bucket count is what the probe phase pays for: a wavefront walks its 256
+//     buckets of a tile in lock step, so a tile costs as many compare rounds as its LONGEST bucket has entries --
+//     7 with 8192 buckets of 1.9 entries on average, 4.6 with 16384 of 0.93 ([measured] 10^9 x 10^9: join kernel
+//     10.1 -> 9.3 ms for 1568 table entries fewer; 17920 entries in 8192 buckets remain as JK_CT_13).
 //   * the probe side streams through a 3-tile register ring; a probe tuple leaves in registers its rowID and its
 //     matches as {first table position of its bucket, bit mask of the matching entries} (the register file, 512 KiB
 //     per CU, is the largest memory there is: it holds a whole 16 K-tuple probe task).  1024 threads x 128 VGPRs:
@@ -1614,15 +1619,18 @@ k_join_bkt(const RelView<NARROW> R, const RelView<NARROW> S, const JoinTask *__r
 //     Several matches per probe tuple (duplicates on the build side: every second partition of a PK/FK join builds on
 //     the foreign-key side, JobScheduler.cpp:187) cost nothing extra.
 //   * when every probe is done the keys are dead: the build rowIDs (re-fetched from the partition, see below) are
-//     written over the table IN TABLE ORDER (each thread kept the 16-bit position of the entries it placed), and the
-//     pairs (rowR,rowS) are completed from LDS.  One global atomicAdd per task reserves the output; matches are compacted
-//     per wavefront slot by ballot + mbcnt; consecutive lanes store consecutive 16 B pairs.
+//     written over the table IN TABLE ORDER (each thread kept the 16-bit position of the entries it placed; 4-byte words
+//     in the narrow format), and the pairs (rowR,rowS) are completed from LDS: the first match of all 16 slots in one
+//     batch of LDS reads.  One global atomicAdd per task reserves the output (issued before the rowIDs go into the table);
+//     matches are compacted per wavefront slot by ballot + mbcnt; consecutive lanes store consecutive 16 B pairs; further
+//     matches of a slot (duplicates on the build side) follow in a second pass.
 //   * buckets of more than 16 entries (a join value repeated many times on the build side, e.g. skew) do not fit the
 //     mask: such (wavefront, tile)s go through a generic loop that re-reads the slot's probe tuple, scans long buckets
 //     with all 64 lanes, reserves its own output range and fetches build rowIDs from the partition in L2/HBM by the
 //     16-bit arrival index every entry carries -- correct for any input, off the fast path's registers.
 // Bucket counts are 16-bit halves of 32-bit LDS words (ds_add_rtn on the word; a half cannot carry: <= 17920 per
-// workgroup), so 8192 buckets cost 16 KiB and the average bucket holds 1.9 entries.
+// workgroup), so 16384 buckets cost 32 KiB.  They lie at LDS offset 0 (their byte offset is their address), the table
+// behind them, the scan scratch last (a compare round may read 15 entries past a bucket's end: never past the allocation).
 // ------------------------------------------------------------------------------------------------
 constexpr int CT_THREADS = 1024, CT_CHUNK = 16352, CT_BUCKET_BITS = 14, CT_EPT = 16, CT_PT = 4, CT_DEPTH = 3;
 // JK_CT_13 (the full-size geometry of rounds 2 and 3 until the bucket count was doubled): 17920 entries, 8192 buckets.  For
@@ -1715,10 +1723,8 @@ k_join_ct(const RelView<NARROW> R, const RelView<NARROW> S, const JoinTask *__re
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int rb = radix_bits;
     const unsigned long long lt = (1ull << lane) - 1ull;
-    // slot k of this thread is probe tuple k * THREADS + tid; slots k < nv are valid
-    const int nv = np > (u32)tid ? (int)((np - (u32)tid + THREADS - 1) / THREADS) : 0;
-
-    const int tid0 = tid, nv0 = nv;
+    // slot k of this thread is probe tuple k * THREADS + tid; slots k < nv are valid (nv: computed where the probe phase starts)
+    const int tid0 = tid;
     // Slot row k holds tuples [k * THREADS, (k + 1) * THREADS) of the chunk / task: whether a row is in use is the same for
     // every thread (a scalar compare and branch).  GUARD: rows beyond the partition are skipped, so a partition that fills
     // half the rows pays for half of them and one geometry serves a range of partition sizes at a cost that follows the
@@ -1731,8 +1737,8 @@ k_join_ct(const RelView<NARROW> R, const RelView<NARROW> S, const JoinTask *__re
         // Addresses and range predicates of the 18 build and 16 probe slots depend only on the thread index: left
         // alone they are hoisted out of this loop into > 100 live registers.  An opaque copy of the thread index per
         // iteration keeps those one-instruction recomputations next to their uses.
-        int tid = tid0, nv = nv0;
-        asm volatile("" : "+v"(tid), "+v"(nv));
+        int tid = tid0;
+        asm volatile("" : "+v"(tid));
         const int nvb = nc > (u32)tid ? (int)((nc - (u32)tid + THREADS - 1) / THREADS) : 0;   // valid build slots
         // ---- build: count per bucket (rank = value before the add), keep {key | rank} and the rowID in registers ----
 #pragma unroll
@@ -1764,7 +1770,7 @@ k_join_ct(const RelView<NARROW> R, const RelView<NARROW> S, const JoinTask *__re
 #pragma unroll
             for (int j = 0; j < WPT; j++) { wd[j] = off32[tid * WPT + j]; loc += (wd[j] & 0xFFFFu) + (wd[j] >> 16); }
             u32 tot;
-            u32 ex = block_excl_scan<THREADS, false>(loc, wsum, tot);
+            u32 ex = block_excl_scan<THREADS, false>(loc, wsum, tot, tid);
 #pragma unroll
             for (int j = 0; j < WPT; j++) {
                 const u32 c0 = wd[j] & 0xFFFFu, c1 = wd[j] >> 16;
@@ -1798,7 +1804,10 @@ k_join_ct(const RelView<NARROW> R, const RelView<NARROW> S, const JoinTask *__re
         u32 deferred = 0;                                                    // wave-uniform: slots left to the generic loop
         u32 ctot = 0;                                                        // matches of this lane
         Both ring[DEPTH][PT];
-        asm volatile("" : "+v"(tid), "+v"(nv));
+        asm volatile("" : "+v"(tid));
+        // (valid probe slots of this thread: recomputed here -- carried from the kernel's start it sat in a spill slot, and
+        // 8 bytes of scratch per thread are 0.5 GB of HBM writes per launch)
+        const int nv = np > (u32)tid ? (int)((np - (u32)tid + THREADS - 1) / THREADS) : 0;
 #pragma unroll
         for (int t = 0; t < DEPTH && t < NT; t++) {
             if (!USED(t * PT, np)) continue;
@@ -1957,11 +1966,13 @@ k_join_ct(const RelView<NARROW> R, const RelView<NARROW> S, const JoinTask *__re
             }
         }
         stamp();                                                             // 5: rowID loads issued
-        if (lane == 0) wtot[w] = wave_total;
+        int tq2 = tid0;                                                      // (opaque: &wtot[w], &wtot[lane] are not worth a spill slot)
+        asm volatile("" : "+v"(tq2));
+        if ((tq2 & 63) == 0) wtot[tq2 >> 6] = wave_total;
         __syncthreads();                                                     // every wavefront is done with the table
         stamp();                                                             // 6: barrier passed
         // the one reservation of the task is on its way to L2 while the rowIDs go into the table
-        const u32 mine = lane < NW ? wtot[lane] : 0u;
+        const u32 mine = (tq2 & 63) < NW ? wtot[tq2 & 63] : 0u;
         const u32 inc = wave_incl_scan(mine, lane);
         const u32 chunk_total = __shfl(inc, NW - 1, 64);
         const u32 wbase = __shfl(inc - mine, w, 64);

@@ -20,6 +20,7 @@ ap.add_argument("--step", type=float, default=1.4)
 ap.add_argument("--reps", type=int, default=3)
 ap.add_argument("--dist", default="uniform")
 ap.add_argument("--sizes", default="")
+ap.add_argument("--bits", default="", help="explicit two-pass plan, e.g. 8,8")
 ap.add_argument("--big", type=int, default=-1, help="force join.big_tables=1 and this join.big_kernel")
 a = ap.parse_args()
 sizes = [int(x) for x in a.sizes.split(",")] if a.sizes else []
@@ -31,6 +32,7 @@ e = rhj.Engine(0)
 if a.big >= 0:
     e.set_option("join.big_tables", 1)
     e.set_option("join.big_kernel", a.big)
+opts = rhj.Opts(2, *[int(x) for x in a.bits.split(",")]) if a.bits else None
 cap = max(sizes)
 dR, dS, dO = e.alloc(16 * cap), e.alloc(16 * cap), e.alloc(16 * (cap + 1024))
 for n in sizes:
@@ -38,16 +40,16 @@ for n in sizes:
     e.generate(GEN_S_ZIPF if a.dist == "zipf" else GEN_S_UNIFORM, dS, n, 0, n, seed=42, theta_milli=900)
     exp = e.expected_pkfk(dS, n)
     e.set_profiling(False)
-    cnt = e.join_dev(dR, n, dS, n, dO, n + 1024)
+    cnt = e.join_dev(dR, n, dS, n, dO, n + 1024, opts=opts)
     ok = (cnt, e.pairs_checksum(dO, cnt)) == exp
     e.sync()
     wall = []
     for _ in range(a.reps):
         t0 = time.perf_counter()
-        e.join_dev(dR, n, dS, n, dO, n + 1024)
+        e.join_dev(dR, n, dS, n, dO, n + 1024, opts=opts)
         wall.append((time.perf_counter() - t0) * 1e3)
     e.set_profiling(True)
-    e.join_dev(dR, n, dS, n, dO, n + 1024)
+    e.join_dev(dR, n, dS, n, dO, n + 1024, opts=opts)
     t = e.timings()
     kern = {k: round(t[k]["ms"], 3) for k in ("hist", "scatter", "join") if t[k]["launches"]}
     w = sorted(wall)[len(wall) // 2]

@@ -1339,6 +1339,15 @@ struct DirectJoin { u32 nb, np, build_is_S, split; u64 *host_count; u32 *done; P
 
 // A partitioned relation as the join kernels read it: 16-byte tuples, or the narrow {payload 8 B, rowID 4 B} arrays that
 // k_scatter_wcn writes (NARROW: the build phase then reads 8 B per tuple and the rowID re-fetch 4 B instead of 16 + 16)
+// Buffer descriptors over a partition slice (k_join_ct): a load is then `descriptor + lane offset (one VGPR for all slot rows)
+// + scalar row offset`, with no vector instruction per load for the address, and a lane beyond `n` tuples reads 0 (the
+// range check of the hardware) -- against an add, a compare, a select and a 64-bit address per load with flat addresses.
+typedef u32 v2u32 __attribute__((ext_vector_type(2)));
+typedef u32 v4u32 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_srd(const void *base, u32 bytes)
+{
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(base), 0, (int)bytes, 0x00020000);
+}
 template <bool NARROW> struct RelView;
 template <> struct RelView<false> {
     typedef u64 Rid;
@@ -1348,6 +1357,17 @@ template <> struct RelView<false> {
     __device__ __forceinline__ u64 payload(u32 i) const { return t[i].payload; }
     __device__ __forceinline__ Rid rowid(u32 i) const { return t[i].key; }
     __device__ __forceinline__ Both both(u32 i) const { const Tup v = t[i]; return Both{v.key, v.payload}; }
+    struct Buf {                                           // n tuples from tuple `first` on; row = first tuple of a slot row
+        __amdgpu_buffer_rsrc_t d;
+        __device__ __forceinline__ u64 payload(u32 row, u32 tid) const
+        { const v2u32 v = __builtin_amdgcn_raw_buffer_load_b64(d, (int)(tid * 16u + 8u), (int)(row * 16u), 0); return (u64)v.x | ((u64)v.y << 32); }
+        __device__ __forceinline__ Rid rowid(u32 row, u32 tid) const
+        { const v2u32 v = __builtin_amdgcn_raw_buffer_load_b64(d, (int)(tid * 16u), (int)(row * 16u), 0); return (u64)v.x | ((u64)v.y << 32); }
+        __device__ __forceinline__ Both both(u32 row, u32 tid) const
+        { const v4u32 v = __builtin_amdgcn_raw_buffer_load_b128(d, (int)(tid * 16u), (int)(row * 16u), 0);
+          return Both{(u64)v.x | ((u64)v.y << 32), (u64)v.z | ((u64)v.w << 32)}; }
+    };
+    __device__ __forceinline__ Buf buf(u32 first, u32 n) const { return Buf{make_srd(t + first, n * 16u)}; }
 };
 template <> struct RelView<true> {
     typedef u32 Rid;
@@ -1358,6 +1378,15 @@ template <> struct RelView<true> {
     __device__ __forceinline__ u64 payload(u32 i) const { return p[i]; }
     __device__ __forceinline__ Rid rowid(u32 i) const { return k[i]; }
     __device__ __forceinline__ Both both(u32 i) const { return Both{k[i], p[i]}; }
+    struct Buf {
+        __amdgpu_buffer_rsrc_t dp, dk;
+        __device__ __forceinline__ u64 payload(u32 row, u32 tid) const
+        { const v2u32 v = __builtin_amdgcn_raw_buffer_load_b64(dp, (int)(tid * 8u), (int)(row * 8u), 0); return (u64)v.x | ((u64)v.y << 32); }
+        __device__ __forceinline__ Rid rowid(u32 row, u32 tid) const
+        { return __builtin_amdgcn_raw_buffer_load_b32(dk, (int)(tid * 4u), (int)(row * 4u), 0); }
+        __device__ __forceinline__ Both both(u32 row, u32 tid) const { return Both{rowid(row, tid), payload(row, tid)}; }
+    };
+    __device__ __forceinline__ Buf buf(u32 first, u32 n) const { return Buf{make_srd(p + first, n * 8u), make_srd(k + first, n * 4u)}; }
 };
 
 // TAGGED (multi-GPU receiver, NARROW only): the low TAG_BITS bits of every payload hold the number of the rank the tuple
@@ -1720,6 +1749,7 @@ k_join_ct(const RelView<NARROW> R, const RelView<NARROW> S, const JoinTask *__re
     const RelView<NARROW> B = (build_is_S ? S : R).at(task.bbeg);
     const RelView<NARROW> P = (build_is_S ? R : S).at(task.pbeg);
     const u32 nb = task.blen, np = task.plen;                                // np <= THREADS * EPT (host: probe_split)
+    const typename RelView<NARROW>::Buf PB = P.buf(0, np);                   // (np * 16 < 2^32)
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int rb = radix_bits;
     const unsigned long long lt = (1ull << lane) - 1ull;
@@ -1734,6 +1764,7 @@ k_join_ct(const RelView<NARROW> R, const RelView<NARROW> S, const JoinTask *__re
 #define USED(k, n) (!GUARD || (u32)(k) * (u32)THREADS < (n))
     for (u32 cb = 0; cb < nb; cb += CHUNK) {
         const u32 nc = (nb - cb < (u32)CHUNK) ? nb - cb : (u32)CHUNK;
+        const typename RelView<NARROW>::Buf BB_ = B.buf(cb, nc);              // this chunk of the build side: lanes past nc read 0
         // Addresses and range predicates of the 18 build and 16 probe slots depend only on the thread index: left
         // alone they are hoisted out of this loop into > 100 live registers.  An opaque copy of the thread index per
         // iteration keeps those one-instruction recomputations next to their uses.
@@ -1752,7 +1783,7 @@ k_join_ct(const RelView<NARROW> R, const RelView<NARROW> S, const JoinTask *__re
 #pragma unroll
             for (int k = k0; k < k0 + BB; k++) {
                 bt[k - k0] = 0;
-                if (USED(k, nc)) bt[k - k0] = B.payload(cb + (k < nvb ? (u32)k * THREADS + tid : 0u));
+                if (USED(k, nc)) bt[k - k0] = BB_.payload((u32)k * THREADS, (u32)tid);
             }
 #pragma unroll
             for (int k = k0; k < k0 + BB; k++) {
@@ -1812,7 +1843,7 @@ k_join_ct(const RelView<NARROW> R, const RelView<NARROW> S, const JoinTask *__re
         for (int t = 0; t < DEPTH && t < NT; t++) {
             if (!USED(t * PT, np)) continue;
 #pragma unroll
-            for (int s = 0; s < PT; s++) ring[t][s] = P.both(t * PT + s < nv ? (u32)(t * PT + s) * THREADS + tid : 0u);
+            for (int s = 0; s < PT; s++) ring[t][s] = PB.both((u32)(t * PT + s) * THREADS, (u32)tid);
         }
 #pragma unroll
         for (int t = 0; t < NT; t++) {
@@ -1837,7 +1868,7 @@ k_join_ct(const RelView<NARROW> R, const RelView<NARROW> S, const JoinTask *__re
             if (t + DEPTH < NT && USED((t + DEPTH) * PT, np)) {               // the slot is free: next tile on its way
 #pragma unroll
                 for (int s = 0; s < PT; s++)
-                    ring[t % DEPTH][s] = P.both((t + DEPTH) * PT + s < nv ? (u32)((t + DEPTH) * PT + s) * THREADS + tid : 0u);
+                    ring[t % DEPTH][s] = PB.both((u32)((t + DEPTH) * PT + s) * THREADS, (u32)tid);
             }
             const bool longb = __ballot(maxlen > CT_MASK_BITS) != 0;         // a long bucket somewhere: the generic loop
             if (!longb) {
@@ -1958,11 +1989,10 @@ k_join_ct(const RelView<NARROW> R, const RelView<NARROW> S, const JoinTask *__re
         {
             int tq = tid0;
             asm volatile("" : "+v"(tq));
-            const int nvq = nc > (u32)tq ? (int)((nc - (u32)tq + THREADS - 1) / THREADS) : 0;
 #pragma unroll
             for (int k = 0; k < BPT; k++) {
                 brid[k] = 0;
-                if (USED(k, nc)) brid[k] = B.rowid(cb + (k < nvq ? (u32)k * THREADS + tq : 0u));
+                if (USED(k, nc)) brid[k] = BB_.rowid((u32)k * THREADS, (u32)tq);
             }
         }
         stamp();                                                             // 5: rowID loads issued

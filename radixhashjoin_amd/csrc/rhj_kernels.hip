@@ -1444,13 +1444,13 @@ k_join_bkt(const RelView<NARROW> R, const RelView<NARROW> S, const JoinTask *__r
     // rowID a pair reports for a probe tuple
     auto probe_rowid = [&](const Both &t) -> u64 { return TAGGED ? (u64)t.key + tbase[ptoff + ((u32)t.payload & (u32)TM)] : (u64)t.key; };
 
+    // Loads go through buffer descriptors (see RelView::Buf): no address arithmetic and no branch per load, lanes past the
+    // end read 0 and are ignored by the `i < n` tests below.  (np * 16 < 2^32: a task's probe side is at most DIRECT_MAX_PROBE.)
+    const typename RelView<NARROW>::Buf PB = P.buf(0, np);
     // first probe tile: in flight while the table is built
     Both p[EPT];
 #pragma unroll
-    for (int k = 0; k < EPT; k++) {
-        const u32 i = (u32)k * THREADS + tid;
-        if (i < np) p[k] = P.both(i);
-    }
+    for (int k = 0; k < EPT; k++) p[k] = PB.both((u32)k * THREADS, (u32)tid);
 
     for (u32 cb = 0; cb < nb; cb += CHUNK) {
         const u32 nc = (nb - cb < (u32)CHUNK) ? nb - cb : (u32)CHUNK;
@@ -1458,11 +1458,9 @@ k_join_bkt(const RelView<NARROW> R, const RelView<NARROW> S, const JoinTask *__r
         for (u32 h = tid; h <= NB; h += THREADS) off[h] = 0;
         Both bt[BPT];
         u32 br[BPT];
+        const typename RelView<NARROW>::Buf BBf = B.buf(cb, nc);
 #pragma unroll
-        for (int k = 0; k < BPT; k++) {
-            const u32 i = (u32)k * THREADS + tid;
-            if (i < nc) bt[k] = B.both(cb + i);
-        }
+        for (int k = 0; k < BPT; k++) bt[k] = BBf.both((u32)k * THREADS, (u32)tid);
         __syncthreads();
 #pragma unroll
         for (int k = 0; k < BPT; k++) {
@@ -1497,10 +1495,7 @@ k_join_bkt(const RelView<NARROW> R, const RelView<NARROW> S, const JoinTask *__r
         for (u32 tb = 0; tb < np; tb += TILE) {
             if (tb != 0 || cb != 0) {
 #pragma unroll
-                for (int k = 0; k < EPT; k++) {
-                    const u32 i = tb + (u32)k * THREADS + tid;
-                    if (i < np) p[k] = P.both(i);
-                }
+                for (int k = 0; k < EPT; k++) p[k] = PB.both(tb + (u32)k * THREADS, (u32)tid);
             }
             u32 cnt[EPT], pre[EPT];
 #pragma unroll

@@ -53,7 +53,7 @@ typedef struct {
     int32_t passes;        /* -1 auto, 0, 1 or 2 */
     int32_t bits1;         /* radix bits of pass 1 (LSBs [0,bits1)), 1..10; 0 = auto */
     int32_t bits2;         /* radix bits of pass 2 (bits [bits1,bits1+bits2)), 1..10; 0 = auto */
-    int32_t probe_split;   /* max probe tuples per join task (skew/load balance); 0 = auto */
+    int32_t probe_split;   /* max probe tuples per join task (skew/load balance); 0 = auto; values above 2^24 act as 2^24 */
 } rhj_opts;
 
 /* per-kernel device time of the LAST rhj_join / rhj_join_dev / stage call, from HIP events on the

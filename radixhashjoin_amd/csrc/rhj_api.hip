@@ -831,6 +831,8 @@ int join_phase_on(rhj_ctx *ctx, const void *d_Rp, const u64 *d_psR, u64 nR, cons
     if (narrow && kind != JK_BKT && !jk_is_ct(kind))
         return fail(ctx, RHJ_E_INVALID, "no bucket-join kernel for narrow partitions under this plan");
     if (join_probe_split(kind) && probe_split > join_probe_split(kind)) probe_split = join_probe_split(kind);
+    // the kernels address a task's probe side through a buffer descriptor of 32-bit byte size (16 B per tuple)
+    if (probe_split > BJ_MAX_PROBE_SPLIT) probe_split = BJ_MAX_PROBE_SPLIT;
     const u64 max_tasks64 = nparts + (nR + nS) / probe_split + 1;
     if (max_tasks64 > 0x7fffffffull) return fail(ctx, RHJ_E_INVALID, "too many join tasks");
     const u32 max_tasks = (u32)max_tasks64;

@@ -24,6 +24,7 @@ constexpr int BJ_BUCKET_BITS = 11;                // 2048 hash buckets (offsets:
 constexpr int BJ_EPT = 8;                         // probe tuples per thread per tile
 constexpr int BJ_TILE = BJ_THREADS * BJ_EPT;      // 4096
 constexpr int BJ_FIT = BJ_CHUNK * 15 / 16;        // plan: average build partition <= 3960 tuples
+constexpr u32 BJ_MAX_PROBE_SPLIT = 1u << 24;      // probe tuples per join task at most (a caller's larger probe_split is clamped: same pairs, more tasks)
 // under a plan of >= 16 bits, average build partitions of CT_GUARDED_FROM ... CT_GUARDED_UPTO tuples go to the compact-table
 // kernel's 6144-entry geometry with row guards (k_join_ct<.., GUARD>): 4 ... 10 of its 12 slot rows in use
 constexpr int CT_GUARDED_FROM = 2048, CT_GUARDED_UPTO = 5120;

@@ -363,3 +363,13 @@ def test_bucket_join_checks_its_radix_bits_contract(engine):
         engine.set_option("join.big_tables", -1)
     for x in (d, st, out):
         x.free()
+
+
+@pytest.mark.parametrize("plan", [Opts(1, 8, 0, 2**31 - 1), Opts(2, 4, 4, 2**31 - 1), Opts(2, 8, 8, 1 << 30)])
+def test_a_huge_probe_split_from_the_caller(engine, oracle, plan):
+    """probe_split is the caller's: the kernels address a task's probe side through a 32-bit buffer descriptor, so values
+    above 2^24 are clamped (include/rhj.h) -- same pairs"""
+    R, S = oracle.gen_R(120_000), oracle.gen_S_counter(500_000, 120_000, 5)
+    got = engine.join(R, S, opts=plan)
+    exp = oracle.join(R, S)
+    assert len(got) == len(exp) and np.array_equal(sorted_pairs(got), sorted_pairs(exp))

@@ -27,6 +27,7 @@
 #define RHJOK(ctx, x) do { int r_ = (x); if (r_ != RHJ_OK) { fprintf(stderr, "%s: %s\n", #x, rhj_last_error(ctx)); exit(2); } } while (0)
 
 static const int SHIFT = 20, BITS = 8, C = 1 << BITS;        // owner classes: payload bits [20, 28)
+static const uint64_t MAX_MSG = (uint64_t)64 << 20;           // tuples per RCCL message at most
 
 // contiguous class ranges of near-equal weight (every rank computes the same cuts from the same gathered histogram)
 static std::vector<int> balanced_cuts(const std::vector<uint64_t> &w, int world)
@@ -93,6 +94,11 @@ int main(int argc, char **argv)
     RHJOK(ctx, rhj_expected_pkfk_dev(ctx, (const rhj_tuple *)dS, n, &exp_cnt, &exp_chk));
 
     const auto t0 = std::chrono::steady_clock::now();
+    const bool tracing = getenv("RHJ_SHARD_TRACE") != nullptr;                // stage markers on stderr (a hang names its stage)
+    auto trace = [&](const char *what) {
+        if (tracing) { fprintf(stderr, "[rank %d, %.1f ms] %s\n", rank, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(), what); fflush(stderr); }
+    };
+    trace("generated");
     // 1. class histograms + rowID ranges
     const int NH = 6;                                   // head words: nR, nS, minR, maxR, minS, maxS
     std::vector<uint64_t> mine(NH + 2 * C);
@@ -108,6 +114,7 @@ int main(int argc, char **argv)
     NCCLOK(ncclAllGather(d_mine, d_all, words, ncclUint64, comm, st));
     std::vector<uint64_t> all(words * world);
     RHJOK(ctx, rhj_copy_d2h(ctx, all.data(), d_all, words * 8 * world));   // (synchronises the stream: sizes must be known)
+    trace("counts gathered");
     auto H = [&](int r, int rel, int c) { return all[(size_t)r * words + NH + rel * C + c]; };
     std::vector<uint64_t> weight(C, 0);
     for (int r = 0; r < world; r++) for (int c = 0; c < C; c++) weight[c] += H(r, 0, c) + H(r, 1, c);
@@ -149,26 +156,43 @@ int main(int argc, char **argv)
         RHJOK(ctx, rhj_dev_alloc(ctx, (m[rel] + 4) * 4, &rK[rel]));
         const uint64_t *sP = (const uint64_t *)sendbuf[rel];
         const uint32_t *sK = (const uint32_t *)((const char *)sendbuf[rel] + rhj_narrow_key_offset(n));
+        // what this rank keeps never enters RCCL: a device copy on the same stream (1 / world of the tuples)
         NCCLOK(ncclGroupStart());
         uint64_t soff = 0;
         for (int d = 0; d < world; d++) {
-            NCCLOK(ncclSend(sP + soff, send[rel][d], ncclUint64, d, comm, st));
-            NCCLOK(ncclSend(sK + soff, send[rel][d], ncclUint32, d, comm, st));
-            NCCLOK(ncclRecv((uint64_t *)rP[rel] + seg[rel][d], recv[rel][d], ncclUint64, d, comm, st));
-            NCCLOK(ncclRecv((uint32_t *)rK[rel] + seg[rel][d], recv[rel][d], ncclUint32, d, comm, st));
+            if (d == rank) {
+                HIPOK(hipMemcpyAsync((uint64_t *)rP[rel] + seg[rel][d], sP + soff, send[rel][d] * 8, hipMemcpyDeviceToDevice, st));
+                HIPOK(hipMemcpyAsync((uint32_t *)rK[rel] + seg[rel][d], sK + soff, send[rel][d] * 4, hipMemcpyDeviceToDevice, st));
+            } else {
+                // no message above MAX_MSG tuples (512 MiB of payloads): a segment of a 10^9-row shard is 1 - 4 GB, and this
+                // image's RCCL mishandles a single message of 1.6 GB at least to oneself (sharded.py _a2a)
+                for (uint64_t o = 0; o < send[rel][d]; o += MAX_MSG) {
+                    const uint64_t c = send[rel][d] - o < MAX_MSG ? send[rel][d] - o : MAX_MSG;
+                    NCCLOK(ncclSend(sP + soff + o, c, ncclUint64, d, comm, st));
+                    NCCLOK(ncclSend(sK + soff + o, c, ncclUint32, d, comm, st));
+                }
+                for (uint64_t o = 0; o < recv[rel][d]; o += MAX_MSG) {
+                    const uint64_t c = recv[rel][d] - o < MAX_MSG ? recv[rel][d] - o : MAX_MSG;
+                    NCCLOK(ncclRecv((uint64_t *)rP[rel] + seg[rel][d] + o, c, ncclUint64, d, comm, st));
+                    NCCLOK(ncclRecv((uint32_t *)rK[rel] + seg[rel][d] + o, c, ncclUint32, d, comm, st));
+                }
+            }
             soff += send[rel][d];
         }
         NCCLOK(ncclGroupEnd());
+        trace("exchange enqueued");
     }
     // 5 + 6. local fused two-pass partition of what arrived, bucket join (global rowIDs restored as `mode` says)
     for (int rel = 0; rel < 2; rel++)
         RHJOK(ctx, rhj_shard_partition(ctx, rel, (const uint64_t *)rP[rel], (const uint32_t *)rK[rel], m[rel], world, seg[rel], row0[rel], &plan, mode));
+    trace("partitions enqueued");
     const uint64_t cap = (m[0] > m[1] ? m[0] : m[1]) + 1024;
     void *d_out;
     RHJOK(ctx, rhj_dev_alloc(ctx, cap * 16, &d_out));
     uint64_t cnt = 0;
     RHJOK(ctx, rhj_shard_join(ctx, (rhj_pair *)d_out, cap, &cnt));
     const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    trace("joined");
 
     // verification: sum over ranks of (count, checksum) == sum of the local closed forms
     uint64_t chk = 0;

@@ -40,6 +40,8 @@ The engine is duck-typed so the exchange logic can be tested on CPU ranks with t
 (tests/test_sharded_gloo.py) and the whole path with the real engine and several ranks on one GPU
 (tests/test_gpu_sharded.py, tests/test_gpu_bench_multirank.py).
 """
+import os
+
 import numpy as np
 import torch
 import torch.distributed as dist
@@ -98,6 +100,8 @@ class ShardedJoin:
         self.rowid_mode = rowid_mode         # tests: SHARD_TAGGED / SHARD_GLOBAL16 instead of what rhj_shard_plan suggests for the sizes
         self.force_exchange = force_exchange # world == 1: run the whole schedule anyway (collectives with oneself): the
         #                                      one-GPU box's way of executing the RCCL code path of a multi-GPU job
+        # no single message of the exchange above this many bytes (see _a2a); RHJ_SHARD_MAX_MSG overrides (tests: small values)
+        self.max_msg_bytes = int(os.environ.get("RHJ_SHARD_MAX_MSG", 512 << 20))
         self.collect_timings = False         # True: sum the engine's per-kernel HIP-event timings over the calls of a join
         #                                      (synchronises after every engine call: for profiling steps, not timed ones)
         self.kernel_ms = {}
@@ -265,6 +269,9 @@ class ShardedJoin:
             recv = [int(allh[src, rel, cuts[self.rank]:cuts[self.rank + 1]].sum()) for src in range(self.world)]
             splits.append((send, recv))
             meta["recvR" if rel == 0 else "recvS"] = [int(allh[:, rel, cuts[d]:cuts[d + 1]].sum()) for d in range(self.world)]
+        # the longest segment any rank sends to any rank (rows): the number of rounds of the exchange must be the same everywhere
+        self._max_seg = max(int(allh[src, rel, cuts[d]:cuts[d + 1]].sum())
+                            for src in range(self.world) for rel in (0, 1) for d in range(self.world))
         return splits
 
     def _local_join_whole(self, Rx, mR, Sx, mS, out):
@@ -314,15 +321,70 @@ class ShardedJoin:
                 acc[0] += v["ms"]
                 acc[1] += v["launches"]
 
+    class _Works:
+        """the work objects of one exchange (several collectives when it was cut into rounds)"""
+        def __init__(self, works):
+            self.works = [w for w in works if w is not None]
+
+        def wait(self):
+            for w in self.works:
+                w.wait()
+
     def _a2a(self, out, inp, out_splits, in_splits, async_op=False):
-        """all_to_all_single; with a backend that cannot move device memory (gloo rehearsal of the
-        multi-rank path on a single-GPU box) the payload is staged through host memory."""
-        if inp.is_cuda and dist.get_backend(self.group) == "gloo":
-            h_in, h_out = inp.cpu(), torch.empty(out.shape, dtype=out.dtype)
-            dist.all_to_all_single(h_out, h_in, out_splits, in_splits, group=self.group)
-            out.copy_(h_out)
+        """The all-to-all of one array (rows of `inp` in destination order, `in_splits[d]` rows to rank d; `out_splits[r]` rows
+        from rank r land in `out` in source order).
+
+        * What this rank keeps (1 / world of the tuples) never enters the collective: a device copy on the current stream.
+        * No message is larger than `max_msg_bytes` (default 512 MiB): larger segments go in rounds, each round one
+          `all_to_all` over views of the two arrays.  [measured, this image] RCCL's copy of a rank's own segment is wrong above
+          about 1 GiB (torch's bundled RCCL: `all_to_all_single` of 1.6 GB on one rank returns at once with other bytes) or never
+          finishes (system RCCL 2.27.7: grouped `ncclSend` + `ncclRecv` to self of 1.6 GB); peer segments of 10^9-row shards are
+          1 - 4 GB (`tools/ab`-style probe: `tests/test_gpu_sharded.py::test_rccl_exchange_of_a_large_self_segment`).
+        * With a backend that cannot move device memory (gloo rehearsal of the multi-rank path on a single-GPU box) the
+          rounds are staged through host memory."""
+        rank, world = self.rank, self.world
+        row_bytes = inp.element_size()
+        for dim in inp.shape[1:]:
+            row_bytes *= int(dim)
+        # world == 1 with force_exchange (the one-GPU way of executing the RCCL path): the own segment goes through the
+        # collective after all, in rounds like a peer's
+        via_self = world == 1 and self.force_exchange
+        in_off = [0]
+        for c in in_splits:
+            in_off.append(in_off[-1] + c)
+        out_off = [0]
+        for c in out_splits:
+            out_off.append(out_off[-1] + c)
+        n_self = in_splits[rank]
+        assert n_self == out_splits[rank]
+        if n_self and not via_self:
+            out[out_off[rank]:out_off[rank] + n_self].copy_(inp[in_off[rank]:in_off[rank] + n_self], non_blocking=True)
+        if world == 1 and not via_self:
             return None
-        return dist.all_to_all_single(out, inp, out_splits, in_splits, group=self.group, async_op=async_op)
+        step = max(1, int(self.max_msg_bytes) // max(row_bytes, 1))
+        peer = lambda d: d != rank or via_self
+        longest = self._max_seg                             # the same number of rounds on every rank (a round may be empty here)
+        gloo = dist.get_backend(self.group) == "gloo"       # no list all_to_all, no device memory: contiguous host pieces
+        works = []
+        for lo in range(0, max(longest, 1), step):
+            def piece(t, off, cnt, d):
+                a = min(lo, cnt) if peer(d) else 0
+                b = min(lo + step, cnt) if peer(d) else 0
+                return t[off + a:off + b]
+            ins = [piece(inp, in_off[d], in_splits[d], d) for d in range(world)]
+            outs = [piece(out, out_off[r], out_splits[r], r) for r in range(world)]
+            if gloo:
+                h_in = torch.cat([t.cpu() for t in ins])
+                h_out = torch.empty((sum(t.shape[0] for t in outs),) + tuple(out.shape[1:]), dtype=out.dtype)
+                dist.all_to_all_single(h_out, h_in, [t.shape[0] for t in outs], [t.shape[0] for t in ins], group=self.group)
+                at = 0
+                for t in outs:
+                    if t.shape[0]:
+                        t.copy_(h_out[at:at + t.shape[0]])
+                    at += t.shape[0]
+            else:
+                works.append(dist.all_to_all(outs, [t.contiguous() for t in ins], group=self.group, async_op=async_op))
+        return self._Works(works) if async_op and works else None
 
     def transport(self):
         """what moves the tuples: for bench.py's config.exchange"""

@@ -156,3 +156,52 @@ def test_sharded_schedule_over_rccl_single_rank(n, D, opts, row0, mode):
     assert p.exitcode == 0
     assert got == exp and same
     assert fmt == "narrow12" and rowid_mode == mode and "RCCL" in transport
+
+
+def rccl_worker_big(port, n, max_msg, q):
+    """one rank over RCCL with a segment larger than one message may be (sharded.py _a2a): verified by count + checksum"""
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    import torch
+    import torch.distributed as dist
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_device(dev)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+    import radixhashjoin_amd as rhj
+    from radixhashjoin_amd.binding import GEN_R, GEN_S_UNIFORM
+    from radixhashjoin_amd.sharded import ShardedJoin
+    stream = torch.cuda.Stream(device=dev)
+    torch.cuda.set_stream(stream)
+    eng = rhj.Engine(0)
+    eng.set_stream(stream.cuda_stream)
+    R = torch.empty((n, 2), dtype=torch.int64, device=dev)
+    S = torch.empty((n, 2), dtype=torch.int64, device=dev)
+    eng.generate(GEN_R, R, n, row0=0, D=n)
+    eng.generate(GEN_S_UNIFORM, S, n, row0=0, D=n, seed=42)
+    exp = eng.expected_pkfk(S, n)
+    sj = ShardedJoin(eng, dist.group.WORLD, force_exchange=True)
+    if max_msg:
+        sj.max_msg_bytes = max_msg
+    cnt, out = sj.join(R, n, S, n)
+    torch.cuda.synchronize()
+    got = (cnt, eng.pairs_checksum(out, cnt))
+    q.put((got, exp, sj.stats["format"], sj.stats.get("rowid_mode"), sj.transport()))
+    eng.close()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("n,max_msg", [(100_000_000, 0), (30_000_000, 16 << 20)])
+def test_rccl_exchange_of_a_large_self_segment(n, max_msg):
+    """10^8 rows = 800 MB of payloads to oneself: two rounds of at most 512 MiB per message (a single 1.6 GB message to
+    oneself comes back wrong from this image's RCCL, see sharded.py _a2a); 3 x 10^7 rows in rounds of 16 MiB"""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=rccl_worker_big, args=(free_port(), n, max_msg, q))
+    p.start()
+    got, exp, fmt, rowid_mode, transport = q.get(timeout=600)
+    p.join(timeout=120)
+    assert p.exitcode == 0
+    assert tuple(got) == tuple(exp) and got[0] == n
+    assert fmt == "narrow12" and rowid_mode == "plain" and "RCCL" in transport

@@ -14,7 +14,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 BIN = os.path.join(ROOT, "radixhashjoin_amd", "host", "sharded_host")
 
 
-@pytest.mark.parametrize("rows,dist_", [(12_000_000, "uniform"), (20_000_000, "zipf")])
+@pytest.mark.parametrize("rows,dist_", [(12_000_000, "uniform"), (20_000_000, "zipf"),
+                                        (200_000_000, "uniform")])     # 1.6 GB kept by the rank: a device copy, not an RCCL message to oneself
 def test_cpp_host_runs_the_sharded_schedule_over_rccl(tmp_path, rows, dist_):
     if not os.path.exists(BIN):
         pytest.skip("sharded_host not built")

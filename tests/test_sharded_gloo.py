@@ -150,6 +150,8 @@ def worker(rank, world, port, n_per_rank, dup, narrow, q, zipf=None, balance=Tru
     # narrow: the 12-byte wire format (needs a two-pass local plan: forced here, the sizes are tiny); else 16-byte tuples
     from radixhashjoin_amd import Opts
     sj = ShardedJoin(OracleEngine(), dist.group.WORLD, balance=balance, narrow=narrow, local_opts=Opts(2, 4, 4) if narrow else None)
+    if os.environ.get("RHJ_TEST_MAX_MSG"):                          # the exchange in rounds of at most this many bytes per message
+        sj.max_msg_bytes = int(os.environ["RHJ_TEST_MAX_MSG"])
     cnt, out = sj.join(shard(Rg), n_per_rank, shard(Sg), n_per_rank)
     if narrow and n_per_rank >= 4_000:
         assert sj.stats["format"] == "narrow12", sj.stats
@@ -201,6 +203,14 @@ def run_world(world, *args):
                                                          (2, 1_000, 1, True), (3, 4_000, 1, True), (3, 4_000, 3, False)])
 def test_sharded_join_equals_global_join(world, n_per_rank, dup, narrow):
     run_world(world, n_per_rank, dup, narrow)
+
+
+@pytest.mark.parametrize("world,n_per_rank,narrow,max_msg", [(2, 20_000, True, 4096), (3, 4_000, False, 1000), (4, 6_000, True, 64)])
+def test_exchange_in_rounds(world, n_per_rank, narrow, max_msg, monkeypatch):
+    """no message of the exchange above max_msg_bytes (sharded.py _a2a: RCCL's limits on this image): segments larger than
+    that travel in several rounds, the own segment by a local copy -- same pair set"""
+    monkeypatch.setenv("RHJ_TEST_MAX_MSG", str(max_msg))
+    run_world(world, n_per_rank, 1, narrow)
 
 
 def test_skewed_join_values_are_balanced_over_ranks():

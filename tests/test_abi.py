@@ -90,3 +90,19 @@ def test_product_never_touches_oracle():
             if f.endswith((".py", ".hip", ".h", ".cpp", ".hpp", "Makefile")):
                 txt = open(os.path.join(dp, f), errors="ignore").read()
                 assert "oracle" not in txt.lower().replace("the cpu oracle", ""), os.path.join(dp, f)
+
+
+def test_shard_plan_modes():
+    """rhj_shard_plan: how a multi-GPU receiver gets global rowIDs back, by the kernel that will join its partitions (the same
+    choice choose_join_kind makes for a single-GPU join of that size)"""
+    from radixhashjoin_amd.binding import SHARD_GLOBAL16, SHARD_PLAIN, SHARD_TAGGED, shard_plan
+    m, p = shard_plan(100_000_000, 100_000_000, None)
+    assert m == SHARD_TAGGED and (p.bits1, p.bits2) == (8, 7)          # 15 bits: the one-table kernel resolves sender tags
+    m, p = shard_plan(200_000_000, 200_000_000, None)
+    assert m == SHARD_GLOBAL16 and (p.bits1, p.bits2) == (8, 8)        # 3 K-tuple partitions: compact-table kernel with row guards
+    m, p = shard_plan(10**9, 10**9, None)
+    assert m == SHARD_GLOBAL16 and (p.bits1, p.bits2) == (8, 8)
+    m, p = shard_plan(1_500_000_000, 1_500_000_000, None)
+    assert m == SHARD_PLAIN and (p.bits1, p.bits2) == (8, 9)           # 17 bits: only rowIDs that need no restoring
+    m, _ = shard_plan(1_000_000, 1_000_000, None)
+    assert m == 0                                                      # one-pass plans: not the narrow sharded path

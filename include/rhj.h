@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define RHJ_ABI_VERSION 2
+#define RHJ_ABI_VERSION 3
 
 /* layout-identical to `struct tuple` (structs.h:33-36): key = rowID, payload = join value */
 typedef struct { uint64_t key; uint64_t payload; } rhj_tuple;
@@ -49,10 +49,26 @@ typedef enum {
  * number of passes and bits per pass are run-time knobs.  0/0 with passes=-1 = automatic:
  * no partitioning when the smaller input fits one LDS hash table, else the fewest bits such
  * that the average build partition fits one LDS table, split over at most two passes. */
+/* WHICH bits.  Inside rhj_join / rhj_join_dev (and the multi-GPU stage calls) the radix digits are bits of
+ *     h = rhj_mix64(payload),   a BIJECTIVE 64-bit mix (splitmix64's finaliser),
+ * not the raw low payload bits: join values that are multiples of 2^16, share their low bits, or differ only in their high
+ * bits would otherwise fall into ONE partition, and a partition far beyond an LDS table is joined in
+ * (probe tasks) x (build chunks) table builds -- quadratic where the reference stays linear (its per-bucket table hashes the
+ * whole value modulo a prime, Result.cpp:43-58).  The first kernel that touches a caller's tuple replaces the payload by h
+ * (histogram digit of h; the scatter writes h); every later kernel compares h, and h == h' <=> payload == payload', so the
+ * pair multiset is unchanged and only rowIDs are ever reported.  Cost: one mix per tuple in two HBM-bound kernels.
+ * What remains: a join value REPEATED n times on both sides yields n^2 pairs under any plan (so does the reference), and
+ * values chosen as rhj_unmix64(k << 16) defeat this fixed mix like any fixed hash; a partition whose build side exceeds the
+ * table is then joined in ceil(build / table) x ceil(probe / probe_split) table builds, correctly.
+ * The public STAGE calls rhj_histogram / rhj_partition / rhj_partition_at / rhj_bucket_join keep RAW payload bits (their
+ * bucket order is the reference's).  rhj_set_option("partition.mix", 0) restores raw bits inside joins (A/B runs, tests). */
+uint64_t rhj_mix64(uint64_t x);
+uint64_t rhj_unmix64(uint64_t h);      /* rhj_unmix64(rhj_mix64(x)) == x */
+
 typedef struct {
     int32_t passes;        /* -1 auto, 0, 1 or 2 */
-    int32_t bits1;         /* radix bits of pass 1 (LSBs [0,bits1)), 1..10; 0 = auto */
-    int32_t bits2;         /* radix bits of pass 2 (bits [bits1,bits1+bits2)), 1..10; 0 = auto */
+    int32_t bits1;         /* radix bits of pass 1 (bits [0,bits1) of h, see above), 1..10; 0 = auto */
+    int32_t bits2;         /* radix bits of pass 2 (bits [bits1,bits1+bits2) of h), 1..10; 0 = auto */
     int32_t probe_split;   /* max probe tuples per join task (skew/load balance); 0 = auto; values above 2^24 act as 2^24 */
 } rhj_opts;
 
@@ -93,11 +109,15 @@ int  rhj_set_profiling(rhj_ctx *ctx, int enabled);
  * "partition.narrow": -1 automatic, 0 never, 1 / 2: inside a join with a two-pass plan, partitions (1) and the
  * intermediate of the two passes (2; the only level of 17-18-bit plans) are stored as {payload 8 B, rowID 4 B} while every
  * rowID is below 2^32 (a larger one is detected on the device -- by the first histogram kernel -- and THAT join repeats itself
- * in the 16-byte format; the next join tries the narrow format again). */
+ * in the 16-byte format; the next join tries the narrow format again);
+ * "partition.mix": -1 automatic (= 1 unless RHJ_MIX=0 is in the environment), 1: joins take their radix digits from
+ * rhj_mix64(payload), 0: from the raw payload (see rhj_opts). */
 int  rhj_set_option(rhj_ctx *ctx, const char *name, int64_t value);
 /* what the last join did: "last.narrow" (0 / 1 / 2, see above), "last.join_kernel" (0 one-table, 1 chunked, 2 / 3
  * compact table full / half size, 4 / 5 the same with 20 probe slots per thread, 6 / 7 the 12288- / 6144-entry geometries, -1 none: direct small join or empty input), "last.pipelined" (the number
- * of S chunks the last rhj_join streamed through the device while finished pairs travelled home; 0: the plain path) */
+ * of S chunks the last rhj_join streamed through the device while finished pairs travelled home; 0: the plain path),
+ * "last.max_part_R" / "last.max_part_S" (tuples in the largest partition of each side the last partitioned join saw; 0 for
+ * an unpartitioned one), "partition.mix" (0 / 1: what joins on this context do) */
 int  rhj_get_info(rhj_ctx *ctx, const char *name, int64_t *value);
 int  rhj_get_timings(rhj_ctx *ctx, rhj_timings *out);
 int  rhj_sync(rhj_ctx *ctx);                             /* JobScheduler::barrier (JobScheduler.cpp:103-122) */
@@ -144,6 +164,12 @@ int rhj_partition(rhj_ctx *ctx, const rhj_tuple *d_in, uint64_t n, int bits1, in
  *   the RCCL all-to-all; the owner bits lie above every bit the local plan uses. */
 int rhj_partition_at(rhj_ctx *ctx, const rhj_tuple *d_in, uint64_t n, int shift, int bits,
                      rhj_tuple *d_out, uint64_t *d_part_start);
+/* rhj_owner_histogram / rhj_owner_split: rhj_histogram / rhj_partition_at with the digit taken from bits [shift, shift+bits)
+ *   of rhj_mix64(payload) instead of the payload; tuples are written UNCHANGED.  The multi-GPU owner split of 16-byte
+ *   tuples (the wire format when the narrow one does not apply): the receiver runs rhj_join_dev on what arrives. */
+int rhj_owner_histogram(rhj_ctx *ctx, const rhj_tuple *d_rel, uint64_t n, int shift, int bits, uint64_t *d_hist);
+int rhj_owner_split(rhj_ctx *ctx, const rhj_tuple *d_in, uint64_t n, int shift, int bits,
+                    rhj_tuple *d_out, uint64_t *d_class_start);
 /* rhj_bucket_join: the JoinJob loop of Result.cpp:98-107 + JoinJob::run + Result::join_buckets +
  *   add_result: for every partition k with both sides non-empty, build an LDS hash table on the smaller
  *   side (S when |R_k| >= |S_k|, JobScheduler.cpp:187) and probe with the other; emit (rowR,rowS).
@@ -158,12 +184,12 @@ int rhj_bucket_join(rhj_ctx *ctx, const rhj_tuple *d_Rp, const uint64_t *d_start
  * histograms, an all-to-all of the tuples over RCCL / xGMI) belong to the host, which may be C++ with rccl.h or Python
  * with torch.distributed (radixhashjoin_amd/sharded.py runs exactly this schedule):
  *
- *   1. rhj_shard_stats  (R, side 0), (S, side 1)     class histogram of the shard at payload bits [shift, shift+bits) and the
- *                                                    range of its rowIDs                                   [16 B/tuple read]
+ *   1. rhj_shard_stats  (R, side 0), (S, side 1)     class histogram of the shard at bits [shift, shift+bits) of
+ *                                                    h = rhj_mix64(payload) and the range of its rowIDs   [16 B/tuple read]
  *   2. all-gather {histograms, rowID ranges}  ->  every rank derives the same contiguous class range per owner and its
  *      send / receive counts; key_base = the shard's smallest rowID (the narrow wire format needs max - min < 2^32)
  *   3. rhj_shard_split  per relation                 class split straight into the NARROW WIRE FORMAT:
- *         payloads  uint64[n]  at d_narrow_out                      (8 B/tuple)
+ *         payloads  uint64[n]  at d_narrow_out, as h = rhj_mix64(payload): what every later stage works on   (8 B/tuple)
  *         rowIDs    uint32[n]  at d_narrow_out + rhj_narrow_key_offset(n), value = rowID - key_base   (4 B/tuple)
  *      tuples of one class contiguous, classes in order: 12 B/tuple cross xGMI instead of 16      [16 B read + 12 B written]
  *   4. all-to-all of the payload array and of the rowID array (same element counts; destination d gets classes
@@ -182,8 +208,8 @@ int rhj_bucket_join(rhj_ctx *ctx, const rhj_tuple *d_Rp, const uint64_t *d_start
  *      global rowIDs, as if one GPU had joined everything.
  * Results stay sharded (every rank holds the pairs of the join values it owns).
  * rhj_shard_plan returns RHJ_SHARD_TAGGED or RHJ_SHARD_GLOBAL16 for sizes / plans that fit this path (the host may use
- * RHJ_SHARD_PLAIN instead when the gathered rowID ranges allow it), or 0: fall back to exchanging 16-byte tuples
- * (rhj_partition_at + all-to-all + rhj_join_dev).
+ * RHJ_SHARD_PLAIN instead when the gathered rowID ranges allow it), RHJ_SHARD_PLAIN for 17-18-bit local plans, or 0: fall back
+ * to exchanging 16-byte tuples (rhj_owner_histogram + rhj_owner_split + all-to-all + rhj_join_dev).
  * Limits: at most 16 ranks (nseg), class bits <= 8, fewer than 2^32 tuples received per relation, a two-pass local plan;
  * 17-18-bit plans (receivers beyond 1.1 * 10^9 tuples) only as RHJ_SHARD_PLAIN, which is what rhj_shard_plan returns for them. */
 #define RHJ_SHARD_TAGGED 1
@@ -220,6 +246,11 @@ int rhj_pairs_checksum_dev(rhj_ctx *ctx, const rhj_pair *d_pairs, uint64_t n, ui
  *   kind 4: constant: T[i] = {i+row0, D} */
 int rhj_generate_dev(rhj_ctx *ctx, int kind, rhj_tuple *d_out, uint64_t n, uint64_t row0, uint64_t D,
                      uint64_t seed, int theta_milli);
+/* Re-labels the join values of a GENERATED relation in place: payload = (k << shift) + add for a payload rhj_mix64(k)
+ *   (kinds 0-3 above).  Applied to both sides of a PK/FK pair of relations it leaves the pair set -- hence
+ *   rhj_expected_pkfk_dev's answer, taken BEFORE the call -- unchanged while the join values become dense (shift 0: the
+ *   value range of the reference's small/ data), multiples of 2^shift, or k * 2^shift + const. */
+int rhj_remap_keys_dev(rhj_ctx *ctx, rhj_tuple *d_rel, uint64_t n, int shift, uint64_t add);
 /* closed-form expectation for PK/FK inputs (R of kind 0 with D == |R| global, unique payloads):
  *   every S tuple {j, mix(k)} matches exactly R row k-1: *count = n, *checksum = sum mix((k-1)*0x100000001B3 ^ mix(j)).
  *   Computed by one streaming pass over S that inverts mix(); does not run the join. */

@@ -17,7 +17,9 @@ from .binding import (  # noqa: F401
     Timings,
     lib_path,
     load_library,
+    mix64,
+    unmix64,
 )
 
-__all__ = ["Engine", "Opts", "Timings", "DeviceBuffer", "RhjError", "TUPLE", "PAIR", "lib_path", "load_library"]
+__all__ = ["Engine", "Opts", "Timings", "DeviceBuffer", "RhjError", "TUPLE", "PAIR", "lib_path", "load_library", "mix64", "unmix64"]
 __version__ = "0.1.0"

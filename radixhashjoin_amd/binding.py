@@ -70,6 +70,10 @@ SYMBOLS = {
     "rhj_prefix": (C.c_int, [_vp, _vp, _u64, _vp]),
     "rhj_partition": (C.c_int, [_vp, _vp, _u64, C.c_int, C.c_int, _vp, _vp]),
     "rhj_partition_at": (C.c_int, [_vp, _vp, _u64, C.c_int, C.c_int, _vp, _vp]),
+    "rhj_owner_histogram": (C.c_int, [_vp, _vp, _u64, C.c_int, C.c_int, _vp]),
+    "rhj_owner_split": (C.c_int, [_vp, _vp, _u64, C.c_int, C.c_int, _vp, _vp]),
+    "rhj_mix64": (_u64, [_u64]),
+    "rhj_unmix64": (_u64, [_u64]),
     "rhj_bucket_join": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _u64, C.c_int, C.c_int, _vp, _u64, _P(_u64)]),
     "rhj_narrow_key_offset": (_u64, [_u64]),
     "rhj_narrow_bytes": (_u64, [_u64]),
@@ -81,6 +85,7 @@ SYMBOLS = {
     "rhj_pairs_checksum_dev": (C.c_int, [_vp, _vp, _u64, _P(_u64)]),
     "rhj_generate_dev": (C.c_int, [_vp, C.c_int, _vp, _u64, _u64, _u64, _u64, C.c_int]),
     "rhj_expected_pkfk_dev": (C.c_int, [_vp, _vp, _u64, _P(_u64), _P(_u64)]),
+    "rhj_remap_keys_dev": (C.c_int, [_vp, _vp, _u64, C.c_int, _u64]),
     "rhj_col_filter": (C.c_int, [_vp, _vp, _vp, _u64, C.c_int, _u64, _vp, _P(_u64)]),
     "rhj_gather_tuples": (C.c_int, [_vp, _vp, _vp, _u64, C.c_int, _vp]),
     "rhj_pairs_split": (C.c_int, [_vp, _vp, _u64, _vp, _vp]),
@@ -120,6 +125,28 @@ def plan(nR, nS, opts=None):
     if rc != RHJ_OK:
         raise RhjError(rc, "bad options")
     return out
+
+
+def mix64(x):
+    """numpy form of rhj_mix64 (include/rhj.h): the bijection whose bits the engine's joins take their radix digits and
+    owner classes from (splitmix64's finaliser).  x: uint64 array or scalar."""
+    with np.errstate(over="ignore"):
+        z = np.asarray(x, dtype=np.uint64) + np.uint64(0x9E3779B97F4A7C15)
+        z = (z ^ (z >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)
+        z = (z ^ (z >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)
+        return z ^ (z >> np.uint64(31))
+
+
+def unmix64(h):
+    """inverse of mix64: unmix64(mix64(x)) == x (tests craft inputs whose MIXED value has a chosen bit pattern)"""
+    with np.errstate(over="ignore"):
+        x = np.asarray(h, dtype=np.uint64)
+        x = x ^ (x >> np.uint64(31)) ^ (x >> np.uint64(62))
+        x = x * np.uint64(0x319642B2D24D8EC3)
+        x = x ^ (x >> np.uint64(27)) ^ (x >> np.uint64(54))
+        x = x * np.uint64(0x96DE1B173F119089)
+        x = x ^ (x >> np.uint64(30)) ^ (x >> np.uint64(60))
+        return x - np.uint64(0x9E3779B97F4A7C15)
 
 
 def narrow_key_offset(n):
@@ -323,6 +350,14 @@ class Engine:
     def partition_at(self, d_in, n, shift, bits, d_out, d_part_start):
         self._chk(self.lib.rhj_partition_at(self.ctx, _addr(d_in), n, shift, bits, _addr(d_out), _addr(d_part_start)))
 
+    def owner_histogram(self, d_rel, n, shift, bits, d_hist):
+        """rhj_histogram on bits of mix64(payload): the multi-GPU owner classes"""
+        self._chk(self.lib.rhj_owner_histogram(self.ctx, _addr(d_rel), n, shift, bits, _addr(d_hist)))
+
+    def owner_split(self, d_in, n, shift, bits, d_out, d_class_start):
+        """rhj_partition_at on bits of mix64(payload), tuples unchanged"""
+        self._chk(self.lib.rhj_owner_split(self.ctx, _addr(d_in), n, shift, bits, _addr(d_out), _addr(d_class_start)))
+
     def bucket_join(self, d_Rp, d_startR, d_Sp, d_startS, nparts, radix_bits, d_out=None, capacity=0,
                     probe_split=0, allow_overflow=False):
         n = _u64()
@@ -389,6 +424,10 @@ class Engine:
 
     def generate(self, kind, d_out, n, row0=0, D=1, seed=0, theta_milli=0):
         self._chk(self.lib.rhj_generate_dev(self.ctx, kind, _addr(d_out), n, row0, D, seed, theta_milli))
+
+    def remap_keys(self, d_rel, n, shift, add=0):
+        """payload = (k << shift) + add for generated payloads mix(k), in place (same PK/FK pair set, aligned / dense join values)"""
+        self._chk(self.lib.rhj_remap_keys_dev(self.ctx, _addr(d_rel), n, shift, add))
 
     def expected_pkfk(self, d_S, n):
         cnt, c = _u64(), _u64()

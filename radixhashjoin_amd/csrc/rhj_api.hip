@@ -129,6 +129,7 @@ struct rhj_ctx {
     u32 cur_probe_split = 0;
     int last_join_kind = -1;
     int last_pipelined = 0;            // S chunks of the last rhj_join (0: not pipelined)
+    u64 last_max_part[2] = {0, 0};     // largest partition of R / S the last task list saw (0: direct join)
     bool counters_clean = false;       // the 64-byte join counters are zero (cleared by the partition phase's first launch)
     int cur_narrow = 0;                // partitions are in the narrow {payload, rowID} format (k_scatter_wcn); 2: so was the intermediate
     DevBuf narrow_flag;                // u32: a rowID >= 2^32 met a narrow scatter -> the join re-runs in the 16-byte format
@@ -148,6 +149,8 @@ struct rhj_ctx {
     int opt_big_tables = -1;           // -1: by average build partition size, 0: never, 1: always use an oversized-partition kernel
     int opt_big_kernel = -1;           // -1: automatic, JK_BKT_BIG: never the compact-table kernel
     int opt_narrow = -1;               // -1: automatic (RHJ_NARROW env: 0, 1 = last pass only, 2), 0: never, 1 / 2: that level
+    int opt_mix = -1;                  // -1: automatic (RHJ_MIX env, default 1), 0: radix digits from the raw low payload bits (rounds 1-3),
+                                       // 1: from mix64(payload) (MIX_STORE, rhj_internal.h)
 };
 
 namespace {
@@ -392,6 +395,13 @@ int resolve_plan(u64 nR, u64 nS, const rhj_opts *in, rhj_opts *out, bool device_
     return RHJ_OK;
 }
 
+// whether the joins of this context take their radix digits from mix64(payload) (MIX_STORE) or from the raw payload
+int join_mix(const rhj_ctx *ctx)
+{
+    static const int env = (int)env_u64("RHJ_MIX", 1, 0, 1);
+    return (ctx->opt_mix >= 0 ? ctx->opt_mix : env) ? MIX_STORE : MIX_NONE;
+}
+
 PassGeom make_geom(u64 n, u32 nseg, int shift, int bits, u64 target_units = PART_TARGET_UNITS)
 {
     PassGeom g;
@@ -413,9 +423,10 @@ PassGeom make_geom(u64 n, u32 nseg, int shift, int bits, u64 target_units = PART
 // `whole_relation`: the pass has ONE segment [0,n) and d_seg_start is this context's seg0 buffer, which the pass then
 // fills together with the unit table in one launch.
 int run_pass(rhj_ctx *ctx, const void *d_in, void *d_out, u64 n, const u64 *d_seg_start, u32 nseg, int shift,
-             int bits, u64 *d_part_start, bool whole_relation = false)
+             int bits, u64 *d_part_start, bool whole_relation = false, int mix = MIX_NONE)
 {
-    const PassGeom g = make_geom(n, nseg, shift, bits);
+    PassGeom g = make_geom(n, nseg, shift, bits);
+    g.mix = mix;
     const size_t nbins = (size_t)1 << bits;
     RHJCHK(ensure(ctx, ctx->unit_start, ((size_t)nseg + 1) * 4));
     RHJCHK(ensure(ctx, ctx->unit_hist, (size_t)g.max_units * nbins * 4));
@@ -471,6 +482,7 @@ int run_pass_pair(rhj_ctx *ctx, const void *d_R, u64 nR, void *outR, u64 *psR, c
     // the first launch also clears the join counters (one memset less in front of a join that is ~10 launches in all)
     RHJCHK(ensure(ctx, ctx->counters, 64));
     h.zero8 = (u64 *)ctx->counters.p;
+    h.mix = join_mix(ctx);                               // (only joins come through here)
     ctx->counters_clean = true;
     static const int kinds[4] = {RHJ_K_AUX, RHJ_K_HIST, RHJ_K_SCAN, RHJ_K_SCATTER};
     for (int phase = 0; phase < 4; phase++) {
@@ -498,12 +510,16 @@ struct FusedIn {
     const u64 *key_bases = nullptr;
 };
 
-int partition_relation_fused(rhj_ctx *ctx, const FusedIn &in, u64 n, int b1, int b2, void *d_out, u64 *d_ps, int narrow = 0)
+// mix (16-byte input only): MIX_STORE inside a join -- the histogram and pass 1 take their digits from mix64(payload) and pass 1
+// writes the mixed value, so that pass 2 and the bucket join work on it unchanged
+int partition_relation_fused(rhj_ctx *ctx, const FusedIn &in, u64 n, int b1, int b2, void *d_out, u64 *d_ps, int narrow = 0,
+                             int mix = MIX_NONE)
 {
     const bool segs = in.P != nullptr;
     // 1024 pass-1 units instead of 2048: every unit flushes a 2^(b1+b2)-bin table, and the scatter does not care
     // ([measured] at 10^9 tuples: histogram 2.54 against 2.74 ms, scatter within noise)
-    const PassGeom g1 = make_geom(n, 1, 0, b1, PART_TARGET_UNITS / 2);
+    PassGeom g1 = make_geom(n, 1, 0, b1, PART_TARGET_UNITS / 2);
+    g1.mix = segs ? MIX_NONE : mix;
     static const u32 want_groups = (u32)env_u64("RHJ_GROUPS", 16, 1, 64);                          // tuning aid
     u32 units1, per, ngroups, groups_per_seg = 0;
     u64 segL[16] = {0};
@@ -555,7 +571,7 @@ int partition_relation_fused(rhj_ctx *ctx, const FusedIn &in, u64 n, int b1, int
     {
         Span s(ctx, RHJ_K_HIST);                        // (16-byte input: also reports a rowID that does not fit the narrow format)
         launch_hist2d_units(ctx->stream, segs ? (const void *)in.P : in.aos, segs, n, g1.L, units1, b1, b2, per, ngroups,
-                            (u32 *)ctx->unit_hist.p, (u32 *)ctx->hist2.p, 0, wide, rng1);
+                            (u32 *)ctx->unit_hist.p, (u32 *)ctx->hist2.p, 0, wide, rng1, g1.mix);
     }
     {
         Span s(ctx, RHJ_K_SCAN);
@@ -601,11 +617,12 @@ int partition_relation_fused(rhj_ctx *ctx, const FusedIn &in, u64 n, int b1, int
     return check_launch(ctx, "fused two-pass partition");
 }
 
-int partition_relation_fused(rhj_ctx *ctx, const void *d_in, u64 n, int b1, int b2, void *d_out, u64 *d_ps, int narrow = 0)
+int partition_relation_fused(rhj_ctx *ctx, const void *d_in, u64 n, int b1, int b2, void *d_out, u64 *d_ps, int narrow = 0,
+                             int mix = MIX_NONE)
 {
     FusedIn in;
     in.aos = d_in;
-    return partition_relation_fused(ctx, in, n, b1, b2, d_out, d_ps, narrow);
+    return partition_relation_fused(ctx, in, n, b1, b2, d_out, d_ps, narrow, mix);
 }
 
 // Two narrow passes with SEPARATE histograms (plans of 17-18 bits: 2^(b1+b2) packed counters do not fit the LDS, so the
@@ -613,7 +630,7 @@ int partition_relation_fused(rhj_ctx *ctx, const void *d_in, u64 n, int b1, int 
 // d_out.  A rowID >= 2^32 raises ctx->narrow_flag in pass 1 (every later kernel of the join returns at once).
 // d_inK != nullptr: the input is narrow already (d_in = payloads, d_inK = rowIDs: a received shard whose rowIDs are global).
 int partition_relation_narrow2(rhj_ctx *ctx, const void *d_in, u64 n, int b1, int b2, void *d_out, u64 *d_ps,
-                               const u32 *d_inK = nullptr)
+                               const u32 *d_inK = nullptr, int mix = MIX_NONE)
 {
     RHJCHK(ensure(ctx, ctx->seg0, 64));
     RHJCHK(ensure(ctx, ctx->part_tmp, (size_t)(n ? n : 1) * 16));
@@ -624,7 +641,8 @@ int partition_relation_narrow2(rhj_ctx *ctx, const void *d_in, u64 n, int b1, in
         const u32 nseg = pass ? 1u << b1 : 1u;
         const u64 *seg_start = pass ? (const u64 *)ctx->ps_1.p : (const u64 *)ctx->seg0.p;
         u64 *part_start = pass ? d_ps : (u64 *)ctx->ps_1.p;
-        const PassGeom g = make_geom(n, nseg, shift, bits);
+        PassGeom g = make_geom(n, nseg, shift, bits);
+        g.mix = (!pass && !d_inK) ? mix : MIX_NONE;       // (the 16-byte input of pass 1; from there on the mixed value is the payload)
         const size_t nbins = (size_t)1 << bits;
         RHJCHK(ensure(ctx, ctx->unit_start, ((size_t)nseg + 1) * 4));
         RHJCHK(ensure(ctx, ctx->unit_hist, (size_t)g.max_units * nbins * 4));
@@ -659,16 +677,16 @@ int partition_relation_narrow2(rhj_ctx *ctx, const void *d_in, u64 n, int b1, in
 }
 
 // Partition one relation with `passes` passes into d_out; boundaries into d_ps[2^(b1+b2) + 1].
-int partition_relation(rhj_ctx *ctx, const void *d_in, u64 n, int passes, int b1, int b2, void *d_out, u64 *d_ps)
+int partition_relation(rhj_ctx *ctx, const void *d_in, u64 n, int passes, int b1, int b2, void *d_out, u64 *d_ps, int mix = MIX_NONE)
 {
     if (passes == 2 && fused_two_pass_ok(b1, b2) && n > 0 && n < ((u64)1 << 32))
-        return partition_relation_fused(ctx, d_in, n, b1, b2, d_out, d_ps);
+        return partition_relation_fused(ctx, d_in, n, b1, b2, d_out, d_ps, 0, mix);
     RHJCHK(ensure(ctx, ctx->seg0, 64));
     u64 *seg0 = (u64 *)ctx->seg0.p;                 // {0, n}: written by the first pass itself
-    if (passes == 1) return run_pass(ctx, d_in, d_out, n, seg0, 1, 0, b1, d_ps, true);
+    if (passes == 1) return run_pass(ctx, d_in, d_out, n, seg0, 1, 0, b1, d_ps, true, mix);
     RHJCHK(ensure(ctx, ctx->part_tmp, (size_t)(n ? n : 1) * 16));
     RHJCHK(ensure(ctx, ctx->ps_1, (((size_t)1 << b1) + 1) * 8));
-    RHJCHK(run_pass(ctx, d_in, ctx->part_tmp.p, n, seg0, 1, 0, b1, (u64 *)ctx->ps_1.p, true));
+    RHJCHK(run_pass(ctx, d_in, ctx->part_tmp.p, n, seg0, 1, 0, b1, (u64 *)ctx->ps_1.p, true, mix));
     return run_pass(ctx, ctx->part_tmp.p, d_out, n, (const u64 *)ctx->ps_1.p, 1u << b1, b1, b2, d_ps);
 }
 
@@ -783,26 +801,27 @@ int partition_phase(rhj_ctx *ctx, const void *d_R, u64 nR, const void *d_S, u64 
     } else {
         const int tb = plan.bits1 + (plan.passes == 2 ? plan.bits2 : 0);
         const size_t np = (size_t)1 << tb;
+        const int mix = join_mix(ctx);
         RHJCHK(ensure(ctx, ctx->ps_R, (np + 1) * 8));
         RHJCHK(ensure(ctx, ctx->ps_S, (np + 1) * 8));
         RHJCHK(ensure(ctx, ctx->part_R, (size_t)(nR ? nR : 1) * 16));
         RHJCHK(ensure(ctx, ctx->part_S, (size_t)(nS ? nS : 1) * 16));
         if (ctx->cur_narrow && !narrow_fused_plan(plan)) {
-            RHJCHK(partition_relation_narrow2(ctx, d_R, nR, plan.bits1, plan.bits2, ctx->part_R.p, (u64 *)ctx->ps_R.p));
+            RHJCHK(partition_relation_narrow2(ctx, d_R, nR, plan.bits1, plan.bits2, ctx->part_R.p, (u64 *)ctx->ps_R.p, nullptr, mix));
             RHJCHK(s_ready());
-            RHJCHK(partition_relation_narrow2(ctx, d_S, nS, plan.bits1, plan.bits2, ctx->part_S.p, (u64 *)ctx->ps_S.p));
+            RHJCHK(partition_relation_narrow2(ctx, d_S, nS, plan.bits1, plan.bits2, ctx->part_S.p, (u64 *)ctx->ps_S.p, nullptr, mix));
         } else if (ctx->cur_narrow) {
-            RHJCHK(partition_relation_fused(ctx, d_R, nR, plan.bits1, plan.bits2, ctx->part_R.p, (u64 *)ctx->ps_R.p, ctx->cur_narrow));
+            RHJCHK(partition_relation_fused(ctx, d_R, nR, plan.bits1, plan.bits2, ctx->part_R.p, (u64 *)ctx->ps_R.p, ctx->cur_narrow, mix));
             RHJCHK(s_ready());
-            RHJCHK(partition_relation_fused(ctx, d_S, nS, plan.bits1, plan.bits2, ctx->part_S.p, (u64 *)ctx->ps_S.p, ctx->cur_narrow));
+            RHJCHK(partition_relation_fused(ctx, d_S, nS, plan.bits1, plan.bits2, ctx->part_S.p, (u64 *)ctx->ps_S.p, ctx->cur_narrow, mix));
         } else if (plan.passes == 1 && plan.bits1 <= PASS_PAIR_MAX_BITS) {
             RHJCHK(s_ready());
             RHJCHK(run_pass_pair(ctx, d_R, nR, ctx->part_R.p, (u64 *)ctx->ps_R.p, d_S, nS, ctx->part_S.p, (u64 *)ctx->ps_S.p,
                                  plan.bits1));
         } else {
-            RHJCHK(partition_relation(ctx, d_R, nR, plan.passes, plan.bits1, plan.bits2, ctx->part_R.p, (u64 *)ctx->ps_R.p));
+            RHJCHK(partition_relation(ctx, d_R, nR, plan.passes, plan.bits1, plan.bits2, ctx->part_R.p, (u64 *)ctx->ps_R.p, mix));
             RHJCHK(s_ready());
-            RHJCHK(partition_relation(ctx, d_S, nS, plan.passes, plan.bits1, plan.bits2, ctx->part_S.p, (u64 *)ctx->ps_S.p));
+            RHJCHK(partition_relation(ctx, d_S, nS, plan.passes, plan.bits1, plan.bits2, ctx->part_S.p, (u64 *)ctx->ps_S.p, mix));
         }
         ctx->cur_R = ctx->part_R.p;
         ctx->cur_S = ctx->part_S.p;
@@ -882,6 +901,8 @@ int join_phase_on(rhj_ctx *ctx, const void *d_Rp, const u64 *d_psR, u64 nR, cons
     if (wide_rowid) return RHJ_RETRY_WIDE;                       // a rowID did not fit 32 bits: nothing of this run is valid
     *out_count = host[0];
     ctx->last.ntasks = (u32)(host[1] & 0xffffffffu);
+    ctx->last_max_part[0] = direct ? 0 : host[2];
+    ctx->last_max_part[1] = direct ? 0 : host[3];
     if (host[5])
         return fail(ctx, RHJ_E_INVALID, "a partition's build side has " + std::to_string(host[5]) +
                                         " tuples (>= 2^32): use more radix bits");
@@ -923,9 +944,10 @@ int partition_and_join(rhj_ctx *ctx, const void *d_R, u64 nR, const void *d_S, u
 // one relation under a resolved two-pass (or one-pass) plan; narrow: the level narrow_level() returned for the join
 int partition_side(rhj_ctx *ctx, const void *d_in, u64 n, const rhj_opts &plan, int narrow, void *part, u64 *ps)
 {
-    if (narrow && !narrow_fused_plan(plan)) return partition_relation_narrow2(ctx, d_in, n, plan.bits1, plan.bits2, part, ps);
-    if (narrow) return partition_relation_fused(ctx, d_in, n, plan.bits1, plan.bits2, part, ps, narrow);
-    return partition_relation(ctx, d_in, n, plan.passes, plan.bits1, plan.bits2, part, ps);
+    const int mix = join_mix(ctx);
+    if (narrow && !narrow_fused_plan(plan)) return partition_relation_narrow2(ctx, d_in, n, plan.bits1, plan.bits2, part, ps, nullptr, mix);
+    if (narrow) return partition_relation_fused(ctx, d_in, n, plan.bits1, plan.bits2, part, ps, narrow, mix);
+    return partition_relation(ctx, d_in, n, plan.passes, plan.bits1, plan.bits2, part, ps, mix);
 }
 
 }  // namespace
@@ -949,6 +971,25 @@ void *rhj_internal_counters(rhj_ctx *ctx)
 extern "C" {
 
 int rhj_abi_version(void) { return RHJ_ABI_VERSION; }
+
+// the bijection joins partition by (rhj_kernels.hip mix64 / unmix64: splitmix64's finaliser and its inverse)
+uint64_t rhj_mix64(uint64_t z)
+{
+    z += 0x9E3779B97F4A7C15ULL;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ULL;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBULL;
+    return z ^ (z >> 31);
+}
+
+uint64_t rhj_unmix64(uint64_t x)
+{
+    x ^= (x >> 31) ^ (x >> 62);
+    x *= 0x319642B2D24D8EC3ULL;
+    x ^= (x >> 27) ^ (x >> 54);
+    x *= 0x96DE1B173F119089ULL;
+    x ^= (x >> 30) ^ (x >> 60);
+    return x - 0x9E3779B97F4A7C15ULL;
+}
 
 int rhj_device_count(void)
 {
@@ -1058,6 +1099,7 @@ int rhj_set_option(rhj_ctx *ctx, const char *name, int64_t value)
         ctx->narrow_fail_streak = ctx->narrow_skip = 0;
         return RHJ_OK;
     }
+    if (n == "partition.mix" && value >= -1 && value <= 1) { ctx->opt_mix = (int)value; return RHJ_OK; }
     return fail(ctx, RHJ_E_INVALID, "rhj_set_option: unknown option or value: " + n);
 }
 
@@ -1068,6 +1110,9 @@ int rhj_get_info(rhj_ctx *ctx, const char *name, int64_t *value)
     if (n == "last.narrow") { *value = ctx->cur_narrow; return RHJ_OK; }
     if (n == "last.join_kernel") { *value = ctx->last_join_kind; return RHJ_OK; }
     if (n == "last.pipelined") { *value = ctx->last_pipelined; return RHJ_OK; }
+    if (n == "last.max_part_R") { *value = (int64_t)ctx->last_max_part[0]; return RHJ_OK; }
+    if (n == "last.max_part_S") { *value = (int64_t)ctx->last_max_part[1]; return RHJ_OK; }
+    if (n == "partition.mix") { *value = join_mix(ctx) != MIX_NONE; return RHJ_OK; }
     return fail(ctx, RHJ_E_INVALID, "rhj_get_info: unknown name: " + n);
 }
 
@@ -1556,28 +1601,42 @@ int rhj_partition(rhj_ctx *ctx, const rhj_tuple *d_in, uint64_t n, int bits1, in
     return partition_relation(ctx, d_in, n, bits2 ? 2 : 1, bits1, bits2, d_out, (u64 *)d_part_start);
 }
 
-int rhj_partition_at(rhj_ctx *ctx, const rhj_tuple *d_in, uint64_t n, int shift, int bits, rhj_tuple *d_out,
-                     uint64_t *d_part_start)
+static int partition_at(rhj_ctx *ctx, const rhj_tuple *d_in, uint64_t n, int shift, int bits, rhj_tuple *d_out,
+                        uint64_t *d_part_start, int mix, const char *who)
 {
     RHJCHK(use_device(ctx));
     if (bits < 1 || bits > PART_MAX_BITS || shift < 0 || shift + bits > 64 || !d_out || !d_part_start || (n && !d_in))
-        return fail(ctx, RHJ_E_INVALID, "bad rhj_partition_at argument");
+        return fail(ctx, RHJ_E_INVALID, std::string("bad argument: ") + who);
     prof_reset(ctx);
     RHJCHK(ensure(ctx, ctx->seg0, 64));
-    return run_pass(ctx, d_in, d_out, n, (const u64 *)ctx->seg0.p, 1, shift, bits, (u64 *)d_part_start, true);
+    return run_pass(ctx, d_in, d_out, n, (const u64 *)ctx->seg0.p, 1, shift, bits, (u64 *)d_part_start, true, mix);
 }
 
-int rhj_histogram(rhj_ctx *ctx, const rhj_tuple *d_rel, uint64_t n, int shift, int bits, uint64_t *d_hist)
+int rhj_partition_at(rhj_ctx *ctx, const rhj_tuple *d_in, uint64_t n, int shift, int bits, rhj_tuple *d_out,
+                     uint64_t *d_part_start)
+{
+    return partition_at(ctx, d_in, n, shift, bits, d_out, d_part_start, MIX_NONE, "rhj_partition_at");
+}
+
+int rhj_owner_split(rhj_ctx *ctx, const rhj_tuple *d_in, uint64_t n, int shift, int bits, rhj_tuple *d_out,
+                    uint64_t *d_class_start)
+{
+    return partition_at(ctx, d_in, n, shift, bits, d_out, d_class_start, MIX_DIGIT, "rhj_owner_split");
+}
+
+static int histogram_of(rhj_ctx *ctx, const rhj_tuple *d_rel, uint64_t n, int shift, int bits, uint64_t *d_hist, int mix,
+                        const char *who)
 {
     RHJCHK(use_device(ctx));
     if (bits < 1 || bits > PART_MAX_BITS || shift < 0 || shift + bits > 64 || !d_hist || (n && !d_rel))
-        return fail(ctx, RHJ_E_INVALID, "bad rhj_histogram argument");
+        return fail(ctx, RHJ_E_INVALID, std::string("bad argument: ") + who);
     prof_reset(ctx);
     const size_t nbins = (size_t)1 << bits;
     RHJCHK(ensure(ctx, ctx->seg0, 64));
     RHJCHK(ensure(ctx, ctx->hist_tmp, (nbins + 1) * 8));
     u64 *seg0 = (u64 *)ctx->seg0.p;
-    const PassGeom g = make_geom(n, 1, shift, bits);
+    PassGeom g = make_geom(n, 1, shift, bits);
+    g.mix = mix;
     RHJCHK(ensure(ctx, ctx->unit_start, 8));
     RHJCHK(ensure(ctx, ctx->unit_hist, (size_t)g.max_units * nbins * 4));
     RHJCHK(ensure(ctx, ctx->unit_base, (size_t)g.max_units * nbins * 8));
@@ -1596,7 +1655,17 @@ int rhj_histogram(rhj_ctx *ctx, const rhj_tuple *d_rel, uint64_t n, int shift, i
                           (u64 *)ctx->unit_base.p, (u64 *)ctx->hist_tmp.p, (u64 *)ctx->scan_tmp.p);
         launch_diff_hist(ctx->stream, (const u64 *)ctx->hist_tmp.p, nbins, (u64 *)d_hist);
     }
-    return check_launch(ctx, "rhj_histogram");
+    return check_launch(ctx, who);
+}
+
+int rhj_histogram(rhj_ctx *ctx, const rhj_tuple *d_rel, uint64_t n, int shift, int bits, uint64_t *d_hist)
+{
+    return histogram_of(ctx, d_rel, n, shift, bits, d_hist, MIX_NONE, "rhj_histogram");
+}
+
+int rhj_owner_histogram(rhj_ctx *ctx, const rhj_tuple *d_rel, uint64_t n, int shift, int bits, uint64_t *d_hist)
+{
+    return histogram_of(ctx, d_rel, n, shift, bits, d_hist, MIX_DIGIT, "rhj_owner_histogram");
 }
 
 int rhj_prefix(rhj_ctx *ctx, const uint64_t *d_hist, uint64_t nbins, uint64_t *d_start)
@@ -1682,7 +1751,8 @@ int rhj_shard_stats(rhj_ctx *ctx, int side, const rhj_tuple *d_rel, uint64_t n, 
     prof_reset(ctx);
     const size_t nbins = (size_t)1 << bits;
     const ShardTables t = shard_tables(ctx, side);
-    const PassGeom g = make_geom(n, 1, shift, bits);
+    PassGeom g = make_geom(n, 1, shift, bits);
+    g.mix = MIX_STORE;                                   // classes are bits of mix64(payload): see rhj.h
     RHJCHK(ensure(ctx, *t.seg0, 64));
     RHJCHK(ensure(ctx, *t.unit_start, 16));
     RHJCHK(ensure(ctx, *t.unit_hist, (size_t)g.max_units * nbins * 4));
@@ -1735,7 +1805,8 @@ int rhj_shard_split(rhj_ctx *ctx, int side, const rhj_tuple *d_rel, uint64_t n, 
     prof_reset(ctx);
     const size_t nbins = (size_t)1 << bits;
     const ShardTables t = shard_tables(ctx, side);
-    const PassGeom g = make_geom(n, 1, shift, bits);
+    PassGeom g = make_geom(n, 1, shift, bits);
+    g.mix = MIX_STORE;                                   // the wire carries mix64(payload); the receiver never mixes again
     RHJCHK(ensure(ctx, ctx->narrow_flag, 64));
     {
         Span s(ctx, RHJ_K_AUX);
@@ -1879,6 +1950,17 @@ int rhj_generate_dev(rhj_ctx *ctx, int kind, rhj_tuple *d_out, uint64_t n, uint6
         launch_generate(ctx->stream, kind, d_out, n, row0, D, seed, theta_milli / 1000.0);
     }
     return check_launch(ctx, "rhj_generate_dev");
+}
+
+int rhj_remap_keys_dev(rhj_ctx *ctx, rhj_tuple *d_rel, uint64_t n, int shift, uint64_t add)
+{
+    RHJCHK(use_device(ctx));
+    if (shift < 0 || shift > 63 || (n && !d_rel)) return fail(ctx, RHJ_E_INVALID, "bad rhj_remap_keys_dev argument");
+    if (n) {
+        Span s(ctx, RHJ_K_AUX);
+        launch_remap_keys(ctx->stream, d_rel, n, shift, add);
+    }
+    return check_launch(ctx, "rhj_remap_keys_dev");
 }
 
 // block sizes are rounded up (64 KiB steps, 1/8 steps above 8 MiB) so that released blocks fit later requests

@@ -51,7 +51,18 @@ struct PassGeom {
     u32 max_units;  // grid size upper bound: floor(n / L) + nseg
     int shift;      // digit = (payload >> shift) & (nbins-1)
     int bits;
+    int mix = 0;    // MIX_*: where the digit comes from when the input is the caller's 16-byte relation
 };
+// Inside a join the radix digits (and, multi-GPU, the owner classes) come from mix64(payload), a BIJECTIVE 64-bit mix
+// (splitmix64's finaliser), not from the raw low payload bits: join values that are multiples of 2^16, or that differ in
+// their high bits only, would otherwise all land in one partition (the reference does not degrade there: its bucket table
+// hashes the whole value modulo a prime, Result.cpp:43-58).  The FIRST kernels that touch the caller's tuples apply it
+// (MIX_STORE: histogram digit of the mixed value; the scatter writes the mixed value), every later kernel -- pass 2, the
+// bucket joins -- works on the mixed value as if it were the payload: a bijection keeps equality, so the pair set does
+// not change, and only rowIDs are reported.  The public stage calls (rhj_histogram / rhj_partition / rhj_partition_at /
+// rhj_bucket_join) keep raw bits: their bucket order is documented.  MIX_DIGIT: digit of the mixed value, tuple written
+// as it came (rhj_shard_split16: the multi-GPU owner split of 16-byte tuples, joined by rhj_join_dev on the receiver).
+constexpr int MIX_NONE = 0, MIX_STORE = 1, MIX_DIGIT = 2;
 
 // launchers (all asynchronous on `st`)
 void launch_init_single_segment(hipStream_t st, u64 n, u64 L, u64 *d_seg_start, u32 *d_unit_start);
@@ -79,6 +90,7 @@ void launch_join_direct(hipStream_t st, const void *d_R, u64 nR, const void *d_S
 void launch_checksum(hipStream_t st, const void *d_pairs, u64 n, u64 *d_sum);
 void launch_generate(hipStream_t st, int kind, void *d_out, u64 n, u64 row0, u64 D, u64 seed, double theta);
 void launch_expected_pkfk(hipStream_t st, const void *d_S, u64 n, u64 *d_sum);
+void launch_remap_keys(hipStream_t st, void *d_rel, u64 n, int shift, u64 add);
 // one partition pass over both relations of a join with shared launches (one-pass plans)
 struct PassSide {
     const void *in;
@@ -91,7 +103,7 @@ struct PassSide {
     u64 *scan_tmp;
     PassGeom g;
 };
-struct PassPairHost { PassSide side[2]; u64 *zero8 = nullptr; /* eight 64-bit words cleared by the first launch, or null */ };
+struct PassPairHost { PassSide side[2]; u64 *zero8 = nullptr; /* eight 64-bit words cleared by the first launch, or null */ int mix = 0; };
 void launch_pass_pair(hipStream_t st, const PassPairHost &h, int shift, int bits, int phase);
 constexpr int PASS_PAIR_MAX_BITS = 9;            // the write-combining scatter's range
 bool fused_two_pass_ok(int b1, int b2);
@@ -111,7 +123,7 @@ int join_ct_min_radix_bits();
 // rowID - key_base does not fit 32 bits.  d_unit_rng (may be null): explicit pass-1 units (launch_seg_units).
 void launch_hist2d_units(hipStream_t st, const void *d_in, bool in_narrow, u64 n, u64 L, u32 units, int b1, int b2,
                          u32 units_per_group, u32 ngroups, u32 *d_hist1, u32 *d_hist2, u64 key_base, u32 *d_wide,
-                         const u64 *d_unit_rng);
+                         const u64 *d_unit_rng, int mix = 0);
 void launch_seg_units(hipStream_t st, u32 nseg, const u64 *seg_off, const u64 *seg_L, u32 units_per_seg, u64 *d_unit_rng,
                       u64 *d_seg_start, u32 *d_unit_start);
 int seg_max();                                             // segments (= ranks) a receiver can tell apart: 16

@@ -150,7 +150,7 @@ struct PassRel {                      // one relation's side of a partition pass
     u64 n, L;
     u32 max_units;
 };
-struct PassPair { PassRel r[2]; };
+struct PassPair { PassRel r[2]; int mix; };
 
 // zero8 (optional): the eight 64-bit join counters, cleared here so that the join phase needs no memset of its own
 __global__ void k_init_single_segment2(PassPair a, u64 *__restrict__ zero8)
@@ -224,7 +224,8 @@ k_hist_units_n(const u64 *__restrict__ inP, const u64 *__restrict__ seg_start, c
 
 __device__ __forceinline__ void
 dev_hist_units(const Tup *__restrict__ in, const u64 *__restrict__ seg_start, const u32 *__restrict__ unit_start,
-               u32 nseg, u64 L, int shift, int bits, u32 *__restrict__ unit_hist, const u32 u, u64 *__restrict__ minmax = nullptr)
+               u32 nseg, u64 L, int shift, int bits, u32 *__restrict__ unit_hist, const u32 u, u64 *__restrict__ minmax = nullptr,
+               int mix = 0)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     u32 *cnt = reinterpret_cast<u32 *>(smem);
@@ -240,13 +241,15 @@ dev_hist_units(const Tup *__restrict__ in, const u64 *__restrict__ seg_start, co
 
     u64 i = beg + threadIdx.x;
     u64 kmin = ~0ull, kmax = 0;                        // range of the rowIDs (minmax != nullptr: the multi-GPU sender's class histogram)
+    // mix != 0: the digit comes from mix64(payload) (inside a join, see MIX_* in rhj_internal.h)
+    auto dig = [&](u64 p) -> u32 { return (u32)((mix ? mix64(p) : p) >> shift) & mask; };
     // 4 independent 16 B loads in flight per lane
     for (; i + 3ull * PART_THREADS < end; i += 4ull * PART_THREADS) {
         const Tup t0 = in[i], t1 = in[i + PART_THREADS], t2 = in[i + 2 * PART_THREADS], t3 = in[i + 3 * PART_THREADS];
-        atomicAdd(&cnt[(u32)(t0.payload >> shift) & mask], 1u);
-        atomicAdd(&cnt[(u32)(t1.payload >> shift) & mask], 1u);
-        atomicAdd(&cnt[(u32)(t2.payload >> shift) & mask], 1u);
-        atomicAdd(&cnt[(u32)(t3.payload >> shift) & mask], 1u);
+        atomicAdd(&cnt[dig(t0.payload)], 1u);
+        atomicAdd(&cnt[dig(t1.payload)], 1u);
+        atomicAdd(&cnt[dig(t2.payload)], 1u);
+        atomicAdd(&cnt[dig(t3.payload)], 1u);
         if (minmax != nullptr) {
             const u64 a = t0.key < t1.key ? t0.key : t1.key, b = t2.key < t3.key ? t2.key : t3.key;
             const u64 c = t0.key > t1.key ? t0.key : t1.key, d = t2.key > t3.key ? t2.key : t3.key;
@@ -257,7 +260,7 @@ dev_hist_units(const Tup *__restrict__ in, const u64 *__restrict__ seg_start, co
     }
     for (; i < end; i += PART_THREADS) {
         const Tup t = in[i];
-        atomicAdd(&cnt[(u32)(t.payload >> shift) & mask], 1u);
+        atomicAdd(&cnt[dig(t.payload)], 1u);
         kmin = t.key < kmin ? t.key : kmin;
         kmax = t.key > kmax ? t.key : kmax;
     }
@@ -277,16 +280,16 @@ dev_hist_units(const Tup *__restrict__ in, const u64 *__restrict__ seg_start, co
 
 __global__ void __launch_bounds__(PART_THREADS)
 k_hist_units(const Tup *__restrict__ in, const u64 *__restrict__ seg_start, const u32 *__restrict__ unit_start,
-             u32 nseg, u64 L, int shift, int bits, u32 *__restrict__ unit_hist, u64 *__restrict__ minmax)
+             u32 nseg, u64 L, int shift, int bits, u32 *__restrict__ unit_hist, u64 *__restrict__ minmax, int mix)
 {
-    dev_hist_units(in, seg_start, unit_start, nseg, L, shift, bits, unit_hist, blockIdx.x, minmax);
+    dev_hist_units(in, seg_start, unit_start, nseg, L, shift, bits, unit_hist, blockIdx.x, minmax, mix);
 }
 
 __global__ void __launch_bounds__(PART_THREADS) k_hist_units2(PassPair a, int shift, int bits)
 {
     const PassRel &x = a.r[blockIdx.y];
     if (blockIdx.x >= x.max_units) return;
-    dev_hist_units(x.in, x.seg_start, x.unit_start, 1u, x.L, shift, bits, x.unit_hist, blockIdx.x);
+    dev_hist_units(x.in, x.seg_start, x.unit_start, 1u, x.L, shift, bits, x.unit_hist, blockIdx.x, nullptr, a.mix);
 }
 
 
@@ -312,7 +315,7 @@ template <bool IN_NARROW>
 __global__ void __launch_bounds__(H2_THREADS)
 k_hist2d_units(const Tup *__restrict__ in, const u64 *__restrict__ inP, u64 n, u64 L, int b1, int b2, u32 units_per_group,
                u32 ngroups, u32 *__restrict__ hist1, u32 *__restrict__ hist2, u64 key_base, u32 *__restrict__ wide,
-               const u64 *__restrict__ unit_rng)
+               const u64 *__restrict__ unit_rng, int mix)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const u32 nb1 = 1u << b1, nb2 = 1u << b2, nbin = nb1 * nb2;
@@ -334,6 +337,7 @@ k_hist2d_units(const Tup *__restrict__ in, const u64 *__restrict__ inP, u64 n, u
     __syncthreads();
 
     auto count = [&](u64 payload) {
+        if (!IN_NARROW && mix) payload = mix64(payload);      // (16-byte input inside a join: digits of the mixed payload)
         const u32 d1 = (u32)payload & m1, d2 = (u32)(payload >> b1) & m2;
         const u32 bin = (d1 << b2) | d2, sh = (bin & 1u) * 16u;
         const u32 old = atomicAdd(&tab[bin >> 1], 1u << sh);
@@ -608,7 +612,7 @@ __global__ void __launch_bounds__(1024) k_scan1_final2(PassPair a, int bits)
 __global__ void __launch_bounds__(PART_THREADS, 4)
 k_scatter_units_pipe(const Tup *__restrict__ in, Tup *__restrict__ out, const u64 *__restrict__ seg_start,
                      const u32 *__restrict__ unit_start, u32 nseg, u64 L, int shift, int bits,
-                     const u64 *__restrict__ unit_base)
+                     const u64 *__restrict__ unit_base, int mix)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const u32 nbins = 1u << bits, mask = nbins - 1;
@@ -626,6 +630,7 @@ k_scatter_units_pipe(const Tup *__restrict__ in, Tup *__restrict__ out, const u6
     const u64 end = (beg + L < send) ? beg + L : send;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const u32 bpl = nbins >= 64 ? nbins >> 6 : 1;                            // bins per lane of the scanning wave
+    auto dig = [&](u64 p) -> u32 { return (u32)((mix == MIX_DIGIT ? mix64(p) : p) >> shift) & mask; };   // (mix: see dev_scatter_wc)
 
     for (u32 b = tid; b < nbins; b += PART_THREADS) { gbase[b] = unit_base[(u64)u * nbins + b]; cnt[b] = 0; }
     __syncthreads();
@@ -645,7 +650,10 @@ k_scatter_units_pipe(const Tup *__restrict__ in, Tup *__restrict__ out, const u6
 #pragma unroll
         for (int k = 0; k < PART_TPT; k++) {
             const u32 i = k * PART_THREADS + tid;
-            if (i < ntile) rk[k] = atomicAdd(&cnt[(u32)(t[k].payload >> shift) & mask], 1u);
+            if (i < ntile) {
+                if (mix == MIX_STORE) t[k].payload = mix64(t[k].payload);
+                rk[k] = atomicAdd(&cnt[dig(t[k].payload)], 1u);
+            }
         }
         __syncthreads();
         if (wave == 0) {
@@ -670,7 +678,7 @@ k_scatter_units_pipe(const Tup *__restrict__ in, Tup *__restrict__ out, const u6
 #pragma unroll
         for (int k = 0; k < PART_TPT; k++) {
             const u32 i = k * PART_THREADS + tid;
-            if (i < ntile) tile[excl[(u32)(t[k].payload >> shift) & mask] + rk[k]] = t[k];
+            if (i < ntile) tile[excl[dig(t[k].payload)] + rk[k]] = t[k];
         }
         __syncthreads();
 #pragma unroll
@@ -680,7 +688,7 @@ k_scatter_units_pipe(const Tup *__restrict__ in, Tup *__restrict__ out, const u6
                 const u32 i = k * PART_THREADS + tid;
                 if (i < ntile) {
                     const Tup v = tile[i];
-                    out[gdelta[(u32)(v.payload >> shift) & mask] + i] = v;
+                    out[gdelta[dig(v.payload)] + i] = v;
                 }
             }
             __builtin_amdgcn_sched_barrier(0);
@@ -739,8 +747,11 @@ __device__ __forceinline__ void
 dev_scatter_wc(const Tup *__restrict__ in, Tup *__restrict__ out, const u64 *__restrict__ seg_start,
                const u32 *__restrict__ unit_start, u32 nseg, u64 L, int shift, int bits,
                const u64 *__restrict__ unit_base, const u64 *__restrict__ unit_rng, u32 n_rng_units, const u32 u,
-               const u64 *__restrict__ inP = nullptr, const u32 *__restrict__ inK = nullptr, u64 key_add = 0)
+               const u64 *__restrict__ inP = nullptr, const u32 *__restrict__ inK = nullptr, u64 key_add = 0, int mix = 0)
 {
+    // mix (16-byte input only, see MIX_* in rhj_internal.h): MIX_STORE -- first pass inside a join: the payload becomes
+    // mix64(payload) as it is loaded, and that is what is written; MIX_DIGIT -- the digit comes from mix64(payload), the tuple
+    // is written as it came (the multi-GPU owner split of 16-byte tuples)
     constexpr int TILE = THREADS * WC_TPT;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const u32 nbins = 1u << bits, mask = nbins - 1;
@@ -769,6 +780,7 @@ dev_scatter_wc(const Tup *__restrict__ in, Tup *__restrict__ out, const u64 *__r
         end = (beg + L < send) ? beg + L : send;
     }
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    auto dig = [&](u64 p) -> u32 { return (u32)((mix == MIX_DIGIT ? mix64(p) : p) >> shift) & mask; };
 
     for (u32 b = tid; b < nbins; b += THREADS) {
         const u64 g = unit_base[(u64)u * nbins + b];
@@ -796,10 +808,14 @@ dev_scatter_wc(const Tup *__restrict__ in, Tup *__restrict__ out, const u64 *__r
         constexpr bool FULL = decltype(full_tag)::value;
         const u32 ntile = FULL ? (u32)TILE : (u32)(end - tb);
         u32 rk[WC_TPT], dg[WC_TPT];
+        if (mix == MIX_STORE) {
+#pragma unroll
+            for (int k = 0; k < WC_TPT; k++) t[k].payload = mix64(t[k].payload);
+        }
 #pragma unroll
         for (int k = 0; k < WC_TPT; k++) {
             const u32 i = k * THREADS + tid;
-            dg[k] = (u32)(t[k].payload >> shift) & mask;
+            dg[k] = dig(t[k].payload);
             if (FULL || i < ntile) rk[k] = atomicAdd(&cnt[dg[k]], 1u);
         }
         __syncthreads();                                                     // B1: counts complete
@@ -858,7 +874,7 @@ dev_scatter_wc(const Tup *__restrict__ in, Tup *__restrict__ out, const u64 *__r
             const u32 i = k * THREADS + tid;
             if (i < mt) {
                 const Tup v = tile[i];
-                const u32 d = (u32)(v.payload >> shift) & mask;
+                const u32 d = dig(v.payload);
                 if (i < T[d]) out[A[d] + i] = v;                              // whole lines [a, b)
                 else keep |= 1u << k;                                         // tail [b, e): carried on
             }
@@ -870,7 +886,7 @@ dev_scatter_wc(const Tup *__restrict__ in, Tup *__restrict__ out, const u64 *__r
                 if (keep & (1u << k)) {
                     const u32 i = k * THREADS + tid;
                     const Tup v = tile[i];
-                    const u32 d = (u32)(v.payload >> shift) & mask;
+                    const u32 d = dig(v.payload);
                     cb[d * 8 + ((u32)(A[d] + i) & 7u)] = v;
                 }
             }
@@ -906,9 +922,10 @@ template <int THREADS>
 __global__ void __launch_bounds__(THREADS)
 k_scatter_wc(const Tup *__restrict__ in, Tup *__restrict__ out, const u64 *__restrict__ seg_start,
              const u32 *__restrict__ unit_start, u32 nseg, u64 L, int shift, int bits,
-             const u64 *__restrict__ unit_base, const u64 *__restrict__ unit_rng, u32 n_rng_units)
+             const u64 *__restrict__ unit_base, const u64 *__restrict__ unit_rng, u32 n_rng_units, int mix)
 {
-    dev_scatter_wc<THREADS>(in, out, seg_start, unit_start, nseg, L, shift, bits, unit_base, unit_rng, n_rng_units, blockIdx.x);
+    dev_scatter_wc<THREADS>(in, out, seg_start, unit_start, nseg, L, shift, bits, unit_base, unit_rng, n_rng_units, blockIdx.x,
+                            nullptr, nullptr, 0, mix);
 }
 
 // narrow in (explicit unit ranges, one sender per unit), 16-byte tuples with global rowIDs out
@@ -930,7 +947,7 @@ __global__ void __launch_bounds__(THREADS) k_scatter_wc2(PassPair a, int shift, 
     const PassRel &x = a.r[blockIdx.y];
     if (blockIdx.x >= x.max_units) return;
     dev_scatter_wc<THREADS>(x.in, x.out, x.seg_start, x.unit_start, 1u, x.L, shift, bits, x.unit_base, (const u64 *)nullptr, 0u,
-                            blockIdx.x);
+                            blockIdx.x, nullptr, nullptr, 0, a.mix);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -966,7 +983,7 @@ k_scatter_wcn(const Tup *__restrict__ in, const u64 *__restrict__ inP, const u32
               u64 *__restrict__ outP, u32 *__restrict__ outK, const u64 *__restrict__ seg_start,
               const u32 *__restrict__ unit_start, u32 nseg, u64 L, int shift, int bits,
               const u64 *__restrict__ unit_base, const u64 *__restrict__ unit_rng, u32 n_rng_units,
-              u32 *__restrict__ overflow, u64 key_base, WnTag tag)
+              u32 *__restrict__ overflow, u64 key_base, WnTag tag, int mix)
 {
     // a rowID that does not fit 32 bits has been seen (by the histogram kernel or by an earlier workgroup of this pass):
     // the join is going to repeat itself in the 16-byte format, nothing written from here on will be read
@@ -1027,6 +1044,12 @@ k_scatter_wcn(const Tup *__restrict__ in, const u64 *__restrict__ inP, const u32
         constexpr bool FULL = decltype(full_tag)::value;
         const u32 ntile = FULL ? (u32)TILE : (u32)(end - tb);
         u32 rk[TPT], dg[TPT];
+        if constexpr (!IN_NARROW) {                                          // first pass inside a join (MIX_STORE): the narrow
+            if (mix) {                                                       // format carries mix64(payload) from here on
+#pragma unroll
+                for (int k = 0; k < TPT; k++) pay[k] = mix64(pay[k]);
+            }
+        }
 #pragma unroll
         for (int k = 0; k < TPT; k++) {
             const u32 i = k * THREADS + tid;
@@ -2123,6 +2146,14 @@ __global__ void __launch_bounds__(256) k_expected_pkfk(const Tup *__restrict__ S
     if (threadIdx.x == 0) atomicAdd(sum, t);
 }
 
+// payload = (k << shift) + add for a generated payload mix64(k): the same PK/FK pair set over join values that are dense
+// (shift 0), multiples of 2^shift, or k * 2^shift + const -- the key shapes that defeat radix digits taken from raw bits
+__global__ void __launch_bounds__(256) k_remap_keys(Tup *__restrict__ t, u64 n, int shift, u64 add)
+{
+    for (u64 i = (u64)blockIdx.x * 256 + threadIdx.x; i < n; i += (u64)gridDim.x * 256)
+        t[i].payload = (unmix64(t[i].payload) << shift) + add;
+}
+
 __global__ void __launch_bounds__(256)
 k_generate(int kind, Tup *__restrict__ out, u64 n, u64 row0, u64 D, u64 seed, double theta)
 {
@@ -2294,7 +2325,7 @@ void launch_hist_units(hipStream_t st, const void *d_in, const PassGeom &g, cons
 {
     if (g.max_units == 0) return;
     hipLaunchKernelGGL(k_hist_units, dim3(g.max_units), dim3(PART_THREADS), ((size_t)4 << g.bits), st,
-                       (const Tup *)d_in, d_seg_start, d_unit_start, g.nseg, g.L, g.shift, g.bits, d_unit_hist, d_minmax);
+                       (const Tup *)d_in, d_seg_start, d_unit_start, g.nseg, g.L, g.shift, g.bits, d_unit_hist, d_minmax, g.mix);
 }
 
 void launch_hist_units_narrow(hipStream_t st, const void *d_inP, const PassGeom &g, const u64 *d_seg_start,
@@ -2332,17 +2363,17 @@ void launch_scatter_units(hipStream_t st, const void *d_in, void *d_out, const P
         if (wc_threads_for(g.bits) == WC_THREADS_SMALL)
             hipLaunchKernelGGL(k_scatter_wc<WC_THREADS_SMALL>, dim3(g.max_units), dim3(WC_THREADS_SMALL),
                                wc_lds_bytes(g.bits, WC_THREADS_SMALL), st, (const Tup *)d_in, (Tup *)d_out, d_seg_start,
-                               d_unit_start, g.nseg, g.L, g.shift, g.bits, d_unit_base, (const u64 *)nullptr, 0u);
+                               d_unit_start, g.nseg, g.L, g.shift, g.bits, d_unit_base, (const u64 *)nullptr, 0u, g.mix);
         else
             hipLaunchKernelGGL(k_scatter_wc<WC_THREADS>, dim3(g.max_units), dim3(WC_THREADS), wc_lds_bytes(g.bits, WC_THREADS),
                                st, (const Tup *)d_in, (Tup *)d_out, d_seg_start, d_unit_start, g.nseg, g.L, g.shift, g.bits,
-                               d_unit_base, (const u64 *)nullptr, 0u);
+                               d_unit_base, (const u64 *)nullptr, 0u, g.mix);
         return;
     }
     // 10-bit pass: carry lines (2^10 x 128 B) do not fit LDS beside a tile -> tile-sort form
     hipLaunchKernelGGL(k_scatter_units_pipe, dim3(g.max_units), dim3(PART_THREADS), part_lds_bytes(g.bits), st,
                        (const Tup *)d_in, (Tup *)d_out, d_seg_start, d_unit_start, g.nseg, g.L, g.shift, g.bits,
-                       d_unit_base);
+                       d_unit_base, g.mix);
 }
 
 // One partition pass over BOTH relations of a join, each kernel launched once (grid.y = relation).  bits <= WC_MAX_BITS.
@@ -2351,6 +2382,7 @@ void launch_pass_pair(hipStream_t st, const PassPairHost &h, int shift, int bits
 {
     allow_big_lds();
     PassPair a;
+    a.mix = h.mix;
     u32 mu = 0;
     for (int i = 0; i < 2; i++) {
         const PassSide &x = h.side[i];
@@ -2386,7 +2418,7 @@ bool fused_two_pass_ok(int b1, int b2) { return b1 >= 1 && b2 >= 1 && b1 <= WC_M
 
 void launch_hist2d_units(hipStream_t st, const void *d_in, bool in_narrow, u64 n, u64 L, u32 units, int b1, int b2,
                          u32 units_per_group, u32 ngroups, u32 *d_hist1, u32 *d_hist2, u64 key_base, u32 *d_wide,
-                         const u64 *d_unit_rng)
+                         const u64 *d_unit_rng, int mix)
 {
     static std::once_flag once[64];
     const size_t lds = ((size_t)1 << (b1 + b2)) * 2 + ((size_t)4 << b1);
@@ -2397,10 +2429,10 @@ void launch_hist2d_units(hipStream_t st, const void *d_in, bool in_narrow, u64 n
     if (units == 0) return;
     if (in_narrow)
         hipLaunchKernelGGL(k_hist2d_units<true>, dim3(units), dim3(H2_THREADS), lds, st, (const Tup *)nullptr, (const u64 *)d_in, n,
-                           L, b1, b2, units_per_group, ngroups, d_hist1, d_hist2, (u64)0, (u32 *)nullptr, d_unit_rng);
+                           L, b1, b2, units_per_group, ngroups, d_hist1, d_hist2, (u64)0, (u32 *)nullptr, d_unit_rng, 0);
     else
         hipLaunchKernelGGL(k_hist2d_units<false>, dim3(units), dim3(H2_THREADS), lds, st, (const Tup *)d_in, (const u64 *)nullptr, n,
-                           L, b1, b2, units_per_group, ngroups, d_hist1, d_hist2, key_base, d_wide, d_unit_rng);
+                           L, b1, b2, units_per_group, ngroups, d_hist1, d_hist2, key_base, d_wide, d_unit_rng, mix);
 }
 
 // pass-1 units cut at segment boundaries (multi-GPU receiver); d_unit_rng gets nseg * units_per_seg + 1 entries
@@ -2433,11 +2465,11 @@ void launch_scatter_ranges(hipStream_t st, const void *d_in, void *d_out, u32 nu
     if (wc_threads_for(bits) == WC_THREADS_SMALL)
         hipLaunchKernelGGL(k_scatter_wc<WC_THREADS_SMALL>, dim3(nunits), dim3(WC_THREADS_SMALL), wc_lds_bytes(bits, WC_THREADS_SMALL),
                            st, (const Tup *)d_in, (Tup *)d_out, (const u64 *)nullptr, (const u32 *)nullptr, 0u, (u64)0, shift,
-                           bits, d_unit_base, d_rng, nunits);
+                           bits, d_unit_base, d_rng, nunits, 0);
     else
         hipLaunchKernelGGL(k_scatter_wc<WC_THREADS>, dim3(nunits), dim3(WC_THREADS), wc_lds_bytes(bits, WC_THREADS), st,
                            (const Tup *)d_in, (Tup *)d_out, (const u64 *)nullptr, (const u32 *)nullptr, 0u, (u64)0, shift, bits,
-                           d_unit_base, d_rng, nunits);
+                           d_unit_base, d_rng, nunits, 0);
 }
 
 // last pass of the multi-GPU receiver in front of the compact-table join: narrow in (rowIDs at narrow_k_offset(n)), 16-byte
@@ -2473,7 +2505,7 @@ void launch_scatter_units_narrow(hipStream_t st, const void *d_in, void *d_out, 
     hipLaunchKernelGGL(k_scatter_wcn<false>, dim3(g.max_units), dim3(WN_THREADS), wn_lds_bytes(g.bits), st, (const Tup *)d_in,
                        (const u64 *)nullptr, (const u32 *)nullptr, (u64 *)d_out,
                        (u32 *)((unsigned char *)d_out + narrow_k_offset(n)), d_seg_start, d_unit_start, g.nseg, g.L, g.shift,
-                       g.bits, d_unit_base, (const u64 *)nullptr, 0u, d_overflow, key_base, WnTag{1u, 1u, 0u});
+                       g.bits, d_unit_base, (const u64 *)nullptr, 0u, d_overflow, key_base, WnTag{1u, 1u, 0u}, g.mix);
 }
 
 // One narrow-output pass over segments cut into units (run_pass form): 16-byte or narrow input, <= 8 bits (32-tuple lines)
@@ -2486,7 +2518,7 @@ void launch_scatter_units_narrow_any(hipStream_t st, const void *d_in, const u32
     const bool in_narrow = d_inK != nullptr;
     const WnTag notag{1u, 1u, 0u};
 #define WCN_ARGS (const Tup *)(in_narrow ? nullptr : d_in), (const u64 *)(in_narrow ? d_in : nullptr), d_inK, (u64 *)d_outP, d_outK,    \
-                 d_seg_start, d_unit_start, g.nseg, g.L, g.shift, g.bits, d_unit_base, (const u64 *)nullptr, 0u, d_overflow, (u64)0, notag
+                 d_seg_start, d_unit_start, g.nseg, g.L, g.shift, g.bits, d_unit_base, (const u64 *)nullptr, 0u, d_overflow, (u64)0, notag, g.mix
     if (g.bits <= WN_MAX_BITS) {
         if (in_narrow) hipLaunchKernelGGL(k_scatter_wcn<true>, dim3(g.max_units), dim3(WN_THREADS), wn_lds_bytes(g.bits), st, WCN_ARGS);
         else hipLaunchKernelGGL(k_scatter_wcn<false>, dim3(g.max_units), dim3(WN_THREADS), wn_lds_bytes(g.bits), st, WCN_ARGS);
@@ -2513,11 +2545,11 @@ void launch_scatter_ranges_narrow(hipStream_t st, const void *d_in, bool in_narr
         hipLaunchKernelGGL(k_scatter_wcn<true>, dim3(nunits), dim3(WN_THREADS), wn_lds_bytes(bits), st, (const Tup *)nullptr,
                            (const u64 *)d_in, d_inK ? d_inK : (const u32 *)((const unsigned char *)d_in + narrow_k_offset(n)), oP, oK,
                            (const u64 *)nullptr, (const u32 *)nullptr, 0u, (u64)0, shift, bits, d_unit_base, d_rng, nunits,
-                           d_overflow, (u64)0, tag);
+                           d_overflow, (u64)0, tag, 0);
     else
         hipLaunchKernelGGL(k_scatter_wcn<false>, dim3(nunits), dim3(WN_THREADS), wn_lds_bytes(bits), st, (const Tup *)d_in,
                            (const u64 *)nullptr, (const u32 *)nullptr, oP, oK, (const u64 *)nullptr, (const u32 *)nullptr, 0u,
-                           (u64)0, shift, bits, d_unit_base, d_rng, nunits, d_overflow, (u64)0, tag);
+                           (u64)0, shift, bits, d_unit_base, d_rng, nunits, d_overflow, (u64)0, tag, 0);
 }
 int tag_bits() { return (int)TAG_BITS; }
 
@@ -2701,6 +2733,11 @@ void launch_checksum(hipStream_t st, const void *d_pairs, u64 n, u64 *d_sum)
 void launch_expected_pkfk(hipStream_t st, const void *d_S, u64 n, u64 *d_sum)
 {
     hipLaunchKernelGGL(k_expected_pkfk, dim3(stream_grid(n)), dim3(256), 0, st, (const Tup *)d_S, n, d_sum);
+}
+
+void launch_remap_keys(hipStream_t st, void *d_rel, u64 n, int shift, u64 add)
+{
+    hipLaunchKernelGGL(k_remap_keys, dim3(stream_grid(n)), dim3(256), 0, st, (Tup *)d_rel, n, shift, add);
 }
 
 void launch_generate(hipStream_t st, int kind, void *d_out, u64 n, u64 row0, u64 D, u64 seed, double theta)

@@ -4,7 +4,10 @@ The reference has no distributed path (single process, pthreads).  S
 both relations are range-sharded by row over the ranks (rowIDs stay global).  The join needs exactly
 ONE exchange step, an all-to-all of tuples by OWNER CLASS:
 
-    class(tuple) = (payload >> owner_shift) & (C - 1)         C = 2^fine_bits classes, C >> world
+    class(tuple) = (mix64(payload) >> owner_shift) & (C - 1)  C = 2^fine_bits classes, C >> world; mix64 = rhj_mix64, the
+                                                              bijection the engine's joins partition by (include/rhj.h):
+                                                              join values that share their raw bits [20,28) -- multiples
+                                                              of 2^28, small dense keys -- still spread over all ranks
     owner(class) = the rank whose contiguous class range [cut[r], cut[r+1]) holds it
 
 Schedule of the narrow path (include/rhj.h "multi-GPU stage entry points"; all compute in the C-ABI engine):
@@ -34,7 +37,8 @@ count.  Results stay sharded: rank d holds the pairs whose join value belongs to
 result is the disjoint union (counts add up, no reduction).
 
 Fallback (16-byte tuples on the wire; `rhj_shard_plan` says 0, or a shard's rowIDs span 2^32 or more, or more than 16
-ranks): rhj_partition_at class split -> all-to-all -> rhj_join_dev locally.
+ranks): rhj_owner_histogram + rhj_owner_split (class of the mixed value, tuples unchanged) -> all-to-all -> rhj_join_dev
+locally.
 
 The engine is duck-typed so the exchange logic can be tested on CPU ranks with the gloo backend
 (tests/test_sharded_gloo.py) and the whole path with the real engine and several ranks on one GPU
@@ -110,7 +114,8 @@ class ShardedJoin:
 
     def owner_of(self, payload):
         """rank that owns the join values `payload` (numpy uint64 array) under the class ranges of the last join"""
-        cls = ((payload >> np.uint64(self.owner_shift)) & np.uint64(self.nclasses - 1)).astype(np.int64)
+        from .binding import mix64
+        cls = ((mix64(payload) >> np.uint64(self.owner_shift)) & np.uint64(self.nclasses - 1)).astype(np.int64)
         return np.searchsorted(np.asarray(self.cuts[1:], dtype=np.int64), cls, side="right")
 
     # ------------------------------------------------------------------------------------------------
@@ -221,7 +226,7 @@ class ShardedJoin:
             staged = torch.empty((max(n, 1), 2), dtype=torch.int64, device=dev)
             bounds = torch.empty(self.nclasses + 1, dtype=torch.int64, device=dev)
             self._fence_torch(dev)
-            eng.partition_at(rel, n, self.owner_shift, self.fine_bits, staged, bounds)
+            eng.owner_split(rel, n, self.owner_shift, self.fine_bits, staged, bounds)
             self._fence_engine()
             m = sum(out_splits)
             recv = torch.empty((max(m, 1), 2), dtype=torch.int64, device=dev)
@@ -238,7 +243,7 @@ class ShardedJoin:
     def _class_histogram(self, rel, n):
         hist = torch.empty(self.nclasses, dtype=torch.int64, device=rel.device)
         self._fence_torch(rel.device)
-        self.engine.histogram(rel, n, self.owner_shift, self.fine_bits, hist)
+        self.engine.owner_histogram(rel, n, self.owner_shift, self.fine_bits, hist)
         self._fence_engine()
         return hist.cpu().numpy()
 

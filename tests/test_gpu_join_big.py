@@ -15,7 +15,7 @@ import pytest
 
 from oracle.pyoracle import PAIR, TUPLE, sorted_pairs
 from radixhashjoin_amd import Engine, Opts
-from radixhashjoin_amd.binding import GEN_CONST, GEN_R, GEN_S_UNIFORM, GEN_S_ZIPF
+from radixhashjoin_amd.binding import GEN_CONST, GEN_R, GEN_S_UNIFORM, GEN_S_ZIPF, unmix64
 
 pytestmark = pytest.mark.gpu
 BKT_BIG, CT, CT_HALF, CT_WIDE, CT_HALF_WIDE, CT_MID, CT_HALF_MID, CT_13, CT_HALF_MID_G = 1, 2, 3, 4, 5, 6, 7, 8, 9
@@ -68,11 +68,11 @@ def rel(rng, n, values, key0=0):
 
 
 def few_partitions(values, nlow):
-    """payload = join value << 16 | one of `nlow` 16-bit patterns chosen BY the value (the same on both sides of a
-    join): a 16-bit radix plan then yields `nlow` large partitions -- what 10^9 tuples give every partition -- from an
-    oracle-sized input"""
+    """payloads whose MIXED value (rhj_mix64, what joins take their radix digits from) is join value << 16 | one of `nlow`
+    16-bit patterns chosen BY the value (the same on both sides of a join): a 16-bit radix plan then yields `nlow` large
+    partitions -- what 10^9 tuples give every partition -- from an oracle-sized input"""
     lows = np.random.default_rng(nlow).permutation(1 << 16)[:nlow].astype(np.uint64)
-    return (values << np.uint64(16)) | lows[(values % np.uint64(nlow)).astype(np.int64)]
+    return unmix64((values << np.uint64(16)) | lows[(values % np.uint64(nlow)).astype(np.int64)])
 
 
 def check(engine, oracle, R, S, plan, wide_rowids=False):
@@ -137,7 +137,7 @@ def test_17_and_18_bit_plans_narrow(big, oracle, plan):
     nR, nS, nlow = 70_000, 160_000, 3
     rv = rng.permutation(1 << 22)[:nR].astype(np.uint64)
     lows = np.random.default_rng(nlow).permutation(1 << tb)[:nlow].astype(np.uint64)
-    R = rel(rng, nR, (rv << np.uint64(tb)) | lows[(rv % np.uint64(nlow)).astype(np.int64)])
+    R = rel(rng, nR, unmix64((rv << np.uint64(tb)) | lows[(rv % np.uint64(nlow)).astype(np.int64)]))      # (mixed value crafted, see few_partitions)
     S = rel(rng, nS, R["payload"][rng.integers(0, nR, nS)], key0=(1 << 32) - nS)
     S["payload"][::97] ^= np.uint64(1 << 50)
     check(big, oracle, R, S, plan)
@@ -162,11 +162,11 @@ def test_long_buckets_cooperative_scan(big, oracle):
     vals = (rng.permutation(1 << 20)[:nb].astype(np.uint64) + np.uint64(1000)) << np.uint64(16)
     vals[:2500] = 17 << 16                 # one hot value
     vals[2500:3100] = 18 << 16             # another
-    B = rel(rng, nb, vals)
+    B = rel(rng, nb, unmix64(vals))        # (the MIXED values share their low 16 bits: one partition, see few_partitions)
     pv = (rng.permutation(1 << 20)[:90_000].astype(np.uint64) + np.uint64(1000)) << np.uint64(16)
     pv[::9001] = 17 << 16                  # ten probe tuples hit the first hot value ...
     pv[5::30_011] = 18 << 16               # ... three the second
-    P = rel(rng, 90_000, pv, key0=(1 << 32) - 90_000)                         # rowIDs up to 2^32 - 1: still narrow
+    P = rel(rng, 90_000, unmix64(pv), key0=(1 << 32) - 90_000)                         # rowIDs up to 2^32 - 1: still narrow
     check(big, oracle, B, P, Opts(2, 8, 8))   # B is the smaller side: build
     check(big, oracle, P, B, Opts(2, 8, 8))   # roles swapped: pairs are (rowR,rowS) either way
     P["key"][77_777] = 1 << 32                                                # one rowID beyond: detected on the device,

@@ -1,0 +1,187 @@
+"""GPU suite: radix digits and owner classes come from a bijective mix of the payload (rhj_mix64, include/rhj.h), not from its
+raw low bits.  The reference's per-bucket table hashes the WHOLE join value modulo a prime (Result.cpp:43-58), so join values
+that are multiples of 2^16, share their low bits or differ only in their high bits cost it nothing; an engine that partitions on
+raw low bits puts all of them into one partition and joins that partition in (probe tasks) x (build chunks) table builds.
+Checked here against the CPU oracle for exactly those key shapes -- k << 16, k << 28, k * 65536 + const, dense i + 1 (the
+value range of the reference's small/ data), k << 48 -- under the automatic plan and forced one- / two-pass plans in
+every tuple format; that the partitions come out balanced ("last.max_part_*"); that the mix can be switched off with the
+same pair set; at 64M x 64M by count + checksum against the closed form, within a bounded time; and the damage that remains
+(one value repeated on both sides) returns in bounded time too."""
+import time
+
+import numpy as np
+import pytest
+
+from oracle.pyoracle import PAIR, TUPLE, sorted_pairs
+from radixhashjoin_amd import Engine, Opts, mix64, unmix64
+from radixhashjoin_amd.binding import GEN_CONST, GEN_R, GEN_S_UNIFORM
+
+pytestmark = pytest.mark.gpu
+
+SHAPES = {
+    "k<<16": lambda k: k << np.uint64(16),
+    "k<<28": lambda k: k << np.uint64(28),
+    "k*65536+const": lambda k: k * np.uint64(65536) + np.uint64(12345),
+    "dense": lambda k: k,                                    # payload = i + 1
+    "k<<48": lambda k: (k & np.uint64(0xFFFF)) << np.uint64(48) | (k >> np.uint64(16)) << np.uint64(20),   # entropy in the high bits
+}
+
+
+def test_numpy_mix_is_the_engines_mix():
+    from radixhashjoin_amd import load_library
+    lib = load_library()
+    xs = np.array([0, 1, 2, 0xFFFFFFFFFFFFFFFF, 1 << 16, 1 << 48, 0x9E3779B97F4A7C15, 123456789012345], dtype=np.uint64)
+    for x, h in zip(xs.tolist(), mix64(xs).tolist()):
+        assert lib.rhj_mix64(x) == h and lib.rhj_unmix64(h) == x
+    assert np.array_equal(unmix64(mix64(xs)), xs)
+
+
+def relations(shape, nR, nS, dup=1, seed=1):
+    """R: nR tuples over nR // dup distinct join values k = 1 ..; S: foreign keys, some of them dangling"""
+    rng = np.random.default_rng(seed)
+    f = SHAPES[shape]
+    D = max(nR // dup, 1)
+    R = np.empty(nR, dtype=TUPLE)
+    R["key"] = rng.permutation(nR).astype(np.uint64)
+    R["payload"] = f(np.uint64(1) + (np.arange(nR, dtype=np.uint64) % np.uint64(D)))
+    S = np.empty(nS, dtype=TUPLE)
+    S["key"] = rng.permutation(nS).astype(np.uint64) + np.uint64(1 << 20)
+    ks = np.uint64(1) + rng.integers(0, D + D // 16 + 1, nS).astype(np.uint64)           # ~6 % beyond D: no partner
+    S["payload"] = f(ks)
+    return R, S
+
+
+def check(engine, oracle, R, S, plan):
+    got = engine.join(R, S, opts=plan)
+    exp = oracle.join(R, S)
+    assert len(got) == len(exp)
+    assert np.array_equal(sorted_pairs(got), sorted_pairs(exp))
+
+
+@pytest.mark.parametrize("shape", list(SHAPES))
+@pytest.mark.parametrize("plan,narrow", [(None, -1), (Opts(1, 8), -1), (Opts(2, 4, 4), 0), (Opts(2, 8, 8), 0), (Opts(2, 8, 8), 2),
+                                         (Opts(2, 8, 9), 2), (Opts(2, 10, 10), 0)])
+def test_aligned_join_values_match_the_oracle(oracle, shape, plan, narrow):
+    R, S = relations(shape, 300_000, 500_000, dup=1 if plan is None else 2)
+    e = Engine(0)
+    try:
+        e.set_option("partition.narrow", narrow)
+        check(e, oracle, R, S, plan)
+        check(e, oracle, S, R, plan)                                      # roles swapped: pairs stay (rowR, rowS)
+        if plan is None:                                                  # 7 bits: 128 partitions of 2.3 K / 3.9 K tuples
+            t = e.timings()
+            nparts = 1 << (t["bits1"] + t["bits2"])
+            assert nparts >= 64
+            assert e.info("last.max_part_R") <= 1.5 * len(S) / nparts + 64         # (after the swap R is the 500 K side)
+            assert e.info("last.max_part_S") <= 1.5 * len(R) / nparts + 64
+    finally:
+        e.close()
+
+
+def test_without_the_mix_the_same_pairs_from_one_partition(oracle):
+    """partition.mix = 0 is rounds 1-3's engine: raw low bits.  Same pair set (a bijection keeps equality, and so does no
+    bijection), but every tuple of a k << 16 relation in ONE of the 2^16 partitions."""
+    R, S = relations("k<<16", 60_000, 90_000)
+    e = Engine(0)
+    try:
+        for mix in (1, 0, -1):
+            e.set_option("partition.mix", mix)
+            assert e.info("partition.mix") == (0 if mix == 0 else 1)
+            check(e, oracle, R, S, Opts(2, 8, 8))
+            biggest = e.info("last.max_part_R")
+            assert biggest == len(R) if mix == 0 else biggest < 64
+        e.set_option("partition.mix", 1)
+        Ru, Su = oracle.gen_R(200_000), oracle.gen_S_counter(300_000, 200_000, 5)
+        got1 = sorted_pairs(e.join(Ru, Su, opts=Opts(1, 6)))
+        e.set_option("partition.mix", 0)
+        assert np.array_equal(sorted_pairs(e.join(Ru, Su, opts=Opts(1, 6))), got1)
+    finally:
+        e.close()
+
+
+def test_public_stage_calls_keep_raw_bits(engine, oracle):
+    """rhj_partition's bucket order is documented (and the reference's for one pass): raw payload bits, mix or no mix"""
+    R, _ = relations("dense", 100_000, 10)
+    dR, dO, dP = engine.to_device(R), engine.alloc(16 * len(R)), engine.alloc(8 * 257)
+    engine.partition(dR, len(R), 8, 0, dO, dP)
+    out, starts = dO.to_numpy(TUPLE, len(R)), dP.to_numpy(np.uint64, 257)
+    for b in (0, 1, 77, 255):
+        assert np.all((out["payload"][int(starts[b]):int(starts[b + 1])] & np.uint64(255)) == b)
+    assert np.array_equal(np.sort(out["payload"]), np.sort(R["payload"]))           # payloads written as they came
+    for x in (dR, dO, dP):
+        x.free()
+
+
+def test_owner_split_classes_of_the_mixed_value(engine):
+    """rhj_owner_histogram / rhj_owner_split: classes = bits [20, 28) of rhj_mix64(payload), tuples unchanged"""
+    R, _ = relations("k<<28", 200_000, 10)
+    n, C = len(R), 256
+    dR, dO, dP, dH = engine.to_device(R), engine.alloc(16 * n), engine.alloc(8 * (C + 1)), engine.alloc(8 * C)
+    engine.owner_histogram(dR, n, 20, 8, dH)
+    engine.owner_split(dR, n, 20, 8, dO, dP)
+    hist, st, out = dH.to_numpy(np.uint64, C), dP.to_numpy(np.uint64, C + 1), dO.to_numpy(TUPLE, n)
+    cls = ((mix64(R["payload"]) >> np.uint64(20)) & np.uint64(C - 1)).astype(np.int64)
+    assert np.array_equal(hist, np.bincount(cls, minlength=C).astype(np.uint64))
+    assert np.array_equal(st, np.concatenate([[0], np.cumsum(hist)]).astype(np.uint64))
+    assert hist.max() < 2 * n / C                                                      # raw bits [20, 28) are all zero
+    got_cls = ((mix64(out["payload"]) >> np.uint64(20)) & np.uint64(C - 1)).astype(np.int64)
+    assert np.array_equal(got_cls, np.repeat(np.arange(C), hist.astype(np.int64)))
+    assert np.array_equal(np.sort(out, order=["key"]), np.sort(R, order=["key"]))
+    for x in (dR, dO, dP, dH):
+        x.free()
+
+
+@pytest.mark.parametrize("shift,add", [(16, 0), (28, 0), (16, 12345), (0, 0)], ids=["k<<16", "k<<28", "k*65536+const", "dense"])
+def test_64m_aligned_join_values_closed_form(engine, shift, add):
+    """64M x 64M PK/FK with re-labelled join values: same pair set as the uniform workload (count + checksum from the closed
+    form, taken before the re-labelling) in about the uniform workload's time -- with digits from raw bits the k << 16 case is
+    ONE partition of 64M tuples (16K table chunks x 4K probe tasks)"""
+    n = 64_000_000
+    dR, dS, dO = engine.alloc(16 * n), engine.alloc(16 * n), engine.alloc(16 * n)
+    try:
+        engine.generate(GEN_R, dR, n, 0, n)
+        engine.generate(GEN_S_UNIFORM, dS, n, 0, n, seed=42)
+        exp_n, exp_c = engine.expected_pkfk(dS, n)
+        engine.join_dev(dR, n, dS, n, dO, n)                                  # warm-up, uniform
+        engine.sync()
+        t0 = time.perf_counter()
+        assert engine.join_dev(dR, n, dS, n, dO, n) == exp_n
+        t_uniform = time.perf_counter() - t0
+        assert engine.pairs_checksum(dO, n) == exp_c
+        engine.remap_keys(dR, n, shift, add)
+        engine.remap_keys(dS, n, shift, add)
+        engine.sync()
+        t0 = time.perf_counter()
+        assert engine.join_dev(dR, n, dS, n, dO, n) == exp_n
+        t_aligned = time.perf_counter() - t0
+        assert engine.pairs_checksum(dO, n) == exp_c
+        t = engine.timings()
+        nparts = 1 << (t["bits1"] + t["bits2"])
+        assert engine.info("last.max_part_R") <= 1.3 * n / nparts + 64
+        assert t_aligned <= 1.3 * t_uniform + 0.002, (t_aligned, t_uniform)
+    finally:
+        for x in (dR, dS, dO):
+            x.free()
+
+
+def test_one_value_repeated_on_both_sides_returns_in_bounded_time(engine):
+    """what no partitioning helps: ONE join value on both sides.  16M x 16 all-equal tuples = 2.56 x 10^8 pairs, one partition
+    under any plan (include/rhj.h states the complexity: ceil(build / table) x ceil(probe / probe_split) table builds; here the
+    16-tuple side is the table).  Bounded: well under a second on the device."""
+    n, m = 16_000_000, 16
+    dR, dS = engine.alloc(16 * n), engine.alloc(16 * m)
+    dO = engine.alloc(16 * n * m)
+    try:
+        engine.generate(GEN_CONST, dR, n, 0, 7)
+        engine.generate(GEN_CONST, dS, m, 0, 7)
+        for plan in (None, Opts(2, 8, 8)):
+            engine.sync()
+            t0 = time.perf_counter()
+            assert engine.join_dev(dR, n, dS, m, dO, n * m, opts=plan) == n * m
+            assert time.perf_counter() - t0 < 2.0
+        part = dO.to_numpy(PAIR, 1_000_000)
+        assert part["keyR"].max() < n and part["keyS"].max() < m
+        assert len(np.unique(part["keyR"] * np.uint64(m) + part["keyS"])) == 1_000_000
+    finally:
+        for x in (dR, dS, dO):
+            x.free()

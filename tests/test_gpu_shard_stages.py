@@ -9,7 +9,8 @@ import pytest
 
 from oracle.pyoracle import TUPLE
 from radixhashjoin_amd import Engine, Opts
-from radixhashjoin_amd.binding import SHARD_GLOBAL16, SHARD_PLAIN, SHARD_TAGGED, narrow_bytes, narrow_key_offset, shard_plan
+from radixhashjoin_amd.binding import (SHARD_GLOBAL16, SHARD_PLAIN, SHARD_TAGGED, mix64, narrow_bytes, narrow_key_offset, shard_plan,
+                                       unmix64)
 from radixhashjoin_amd.sharded import balanced_cuts
 
 pytestmark = pytest.mark.gpu
@@ -18,9 +19,10 @@ BKT, CT, CT_HALF = 0, 2, 3
 
 
 def few_partitions(values, nlow):
-    """payload = join value << 16 | one of `nlow` 16-bit patterns chosen by the value: large partitions under a 16-bit plan"""
+    """payloads whose MIXED value (rhj_mix64: what the engine partitions by) is join value << 16 | one of `nlow` 16-bit
+    patterns chosen by the value: large partitions under a 16-bit plan"""
     lows = np.random.default_rng(nlow).permutation(1 << 16)[:nlow].astype(np.uint64)
-    return (values << np.uint64(16)) | lows[(values % np.uint64(nlow)).astype(np.int64)]
+    return unmix64((values << np.uint64(16)) | lows[(values % np.uint64(nlow)).astype(np.int64)])
 
 
 def sharded_join(eng, shardsR, shardsS, plan, mode):
@@ -33,7 +35,7 @@ def sharded_join(eng, shardsR, shardsS, plan, mode):
             n = len(t)
             d = eng.to_device(t)
             hist, kmin, kmax = eng.shard_stats(side, d, n, SHIFT, BITS)
-            dig = ((t["payload"] >> np.uint64(SHIFT)) & np.uint64(C - 1)).astype(np.int64)
+            dig = ((mix64(t["payload"]) >> np.uint64(SHIFT)) & np.uint64(C - 1)).astype(np.int64)       # classes: bits of the mixed value
             assert np.array_equal(hist, np.bincount(dig, minlength=C))
             assert (kmin, kmax) == (int(t["key"].min()), int(t["key"].max()))
             buf = eng.alloc(max(narrow_bytes(n), 16))
@@ -51,7 +53,7 @@ def sharded_join(eng, shardsR, shardsS, plan, mode):
                 seg = slice(int(st[c]), int(st[c + 1]))
                 assert np.all(((P[seg] >> np.uint64(SHIFT)) & np.uint64(C - 1)) == c)
             a = np.sort(np.stack([P, K.astype(np.uint64) + np.uint64(kmin)], axis=1).view([("p", "<u8"), ("k", "<u8")]).ravel(), order=["k"])
-            b = np.sort(np.stack([t["payload"], t["key"]], axis=1).view([("p", "<u8"), ("k", "<u8")]).ravel(), order=["k"])
+            b = np.sort(np.stack([mix64(t["payload"]), t["key"]], axis=1).view([("p", "<u8"), ("k", "<u8")]).ravel(), order=["k"])   # the wire carries the mixed value
             assert np.array_equal(a, b)
             sent[side].append((P, K, st, kmin))
             for x in (d, buf, starts):
@@ -160,14 +162,14 @@ def test_lopsided_segments(oracle):
     rng = np.random.default_rng(77)
     Rs, Ss = [], []
     for r in range(world):
-        # class = payload bits [20, 28) = value bits [4, 12): shard r only has classes [64 r, 64 r + 64)
+        # class = bits [20, 28) of the mixed payload = value bits [4, 12): shard r only has classes [64 r, 64 r + 64)
         hi = rng.permutation(1 << 12)[:n_per // 8].astype(np.uint64)                     # value bits [12, 24)
         vals = (hi[rng.integers(0, len(hi), n_per)] << np.uint64(12)) | (np.uint64(64 * r) + rng.integers(0, 64, n_per).astype(np.uint64)) << np.uint64(4) \
             | rng.integers(0, 16, n_per).astype(np.uint64)
         for dst, v in ((Rs, vals), (Ss, vals[rng.permutation(n_per)])):
             t = np.empty(n_per, dtype=TUPLE)
             t["key"] = rng.permutation(n_per).astype(np.uint64) + np.uint64(r * (5 << 30))
-            t["payload"] = (v << np.uint64(16)) | np.uint64(0xBEEF)
+            t["payload"] = unmix64((v << np.uint64(16)) | np.uint64(0xBEEF))
             dst.append(t)
     mode, plan = shard_plan(n_per, n_per, Opts(2, 8, 8))
     eng = Engine(0)

@@ -38,6 +38,21 @@ class OracleEngine:
         dig = ((a[:, 1].astype(np.uint64) >> np.uint64(shift)) & np.uint64((1 << bits) - 1)).astype(np.int64)
         d_hist.numpy()[:] = np.bincount(dig, minlength=1 << bits)
 
+    # the owner classes are bits of rhj_mix64(payload) (include/rhj.h); the 16-byte split leaves the tuples as they are
+    def owner_split(self, d_in, n, shift, bits, d_out, d_class_start):
+        from radixhashjoin_amd.binding import mix64
+        a = self._np(d_in, n)
+        dig = ((mix64(a[:, 1].astype(np.uint64)) >> np.uint64(shift)) & np.uint64((1 << bits) - 1)).astype(np.int64)
+        order = np.argsort(dig, kind="stable")
+        d_out.numpy()[:n] = a[order]
+        d_class_start.numpy()[:] = np.concatenate([[0], np.cumsum(np.bincount(dig, minlength=1 << bits))])
+
+    def owner_histogram(self, d_rel, n, shift, bits, d_hist):
+        from radixhashjoin_amd.binding import mix64
+        a = self._np(d_rel, n)
+        dig = ((mix64(a[:, 1].astype(np.uint64)) >> np.uint64(shift)) & np.uint64((1 << bits) - 1)).astype(np.int64)
+        d_hist.numpy()[:] = np.bincount(dig, minlength=1 << bits)
+
     def partition(self, d_in, n, bits1, bits2, d_out, d_part_start):
         # layout documented in include/rhj.h: pass-1 digit major, pass-2 digit minor
         a = self._np(d_in, n)
@@ -61,21 +76,22 @@ class OracleEngine:
 
     # ---- the narrow wire format (include/rhj.h "multi-GPU stage entry points"), restated with numpy ----------------
     def shard_stats(self, side, d_rel, n, shift, bits):
+        from radixhashjoin_amd.binding import mix64
         a = self._np(d_rel, n).view(np.uint64)
-        dig = ((a[:, 1] >> np.uint64(shift)) & np.uint64((1 << bits) - 1)).astype(np.int64)
+        dig = ((mix64(a[:, 1]) >> np.uint64(shift)) & np.uint64((1 << bits) - 1)).astype(np.int64)
         self._dig = getattr(self, "_dig", {})
         self._dig[side] = dig
         return (np.bincount(dig, minlength=1 << bits).astype(np.int64), int(a[:, 0].min()) if n else 0,
                 int(a[:, 0].max()) if n else 0)
 
     def shard_split(self, side, d_rel, n, shift, bits, key_base, d_narrow_out, d_class_start=None):
-        from radixhashjoin_amd.binding import narrow_key_offset
+        from radixhashjoin_amd.binding import mix64, narrow_key_offset
         a = self._np(d_rel, n).view(np.uint64)
         order = np.argsort(self._dig[side], kind="stable")
         local = a[order, 0] - np.uint64(key_base)
         assert np.all(local < np.uint64(1 << 32))
         buf = d_narrow_out.numpy()
-        buf[:8 * n] = a[order, 1].view(np.uint8)
+        buf[:8 * n] = np.ascontiguousarray(mix64(a[order, 1])).view(np.uint8)      # the wire carries the mixed value
         koff = narrow_key_offset(n)
         buf[koff:koff + 4 * n] = local.astype(np.uint32).view(np.uint8)
 
@@ -127,7 +143,7 @@ def zipf_payloads(o, n, D, theta, seed):
     return lut[r]
 
 
-def worker(rank, world, port, n_per_rank, dup, narrow, q, zipf=None, balance=True):
+def worker(rank, world, port, n_per_rank, dup, narrow, q, zipf=None, balance=True, aligned=0):
     sys.path.insert(0, ROOT)
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
@@ -140,6 +156,10 @@ def worker(rank, world, port, n_per_rank, dup, narrow, q, zipf=None, balance=Tru
     Rg, Sg = o.gen_R(nglob, D), o.gen_S_counter(nglob, D, 42)       # global relations, rows range-sharded
     if zipf is not None:
         Sg["payload"] = zipf_payloads(o, nglob, D, zipf, 7)         # skewed foreign key, same array on every rank
+    if aligned:                                                     # join values k << aligned: raw bits [20,28) all zero
+        from radixhashjoin_amd.binding import unmix64
+        for t in (Rg, Sg):
+            t["payload"] = unmix64(t["payload"]) << np.uint64(aligned)
     lo, hi = rank * n_per_rank, (rank + 1) * n_per_rank
 
     def shard(t):
@@ -213,8 +233,18 @@ def test_exchange_in_rounds(world, n_per_rank, narrow, max_msg, monkeypatch):
     run_world(world, n_per_rank, 1, narrow)
 
 
+@pytest.mark.parametrize("narrow", [True, False])
+def test_aligned_join_values_spread_over_ranks(narrow):
+    """join values that are multiples of 2^28 (raw owner bits [20,28) all zero: with classes taken from the raw payload every
+    tuple went to rank 0, and balanced_cuts cannot split a class): classes are bits of rhj_mix64(payload), so every rank
+    receives its share even with equal-width class ranges -- and the pair set is the global join's"""
+    stats = run_world(4, 6_000, 1, narrow, None, False, 28)
+    r = stats["received_per_rank"]
+    assert max(r) / (sum(r) / len(r)) <= 1.15, r
+
+
 def test_skewed_join_values_are_balanced_over_ranks():
-    """Zipf(1.25) foreign key: the hottest join value alone is ~a fifth of S.  Equal-width class ranges (a static
+    """Zipf(1.4) foreign key: the hottest join value alone is ~a third of S.  Equal-width class ranges (a static
     radix map) overload the rank that owns it; ranges cut from the all-gathered class histogram keep every rank
     within 1.3x of the mean, with the same pair set."""
     world, n = 4, 12_000
@@ -223,7 +253,7 @@ def test_skewed_join_values_are_balanced_over_ranks():
         r = stats["received_per_rank"]
         return max(r) / (sum(r) / len(r))
 
-    static = imbalance(run_world(world, n, 1, True, 1.25, False))
-    balanced = imbalance(run_world(world, n, 1, True, 1.25, True))
+    static = imbalance(run_world(world, n, 1, True, 1.4, False))
+    balanced = imbalance(run_world(world, n, 1, True, 1.4, True))
     assert static > 1.3, static                    # the input really is skewed enough to matter
     assert balanced <= 1.3, balanced

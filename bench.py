@@ -14,7 +14,10 @@ N == 1 : 1B x 1B uniform uint64 PK/FK join (BASELINE.json configs[2], the config
          closed form (rhj_expected_pkfk_dev), which tests/ pin to the CPU oracle.
 N  > 1 : weak scaling: the global relations (N x 1B rows each) are range-sharded by row over the
          ranks; one RCCL all-to-all over xGMI redistributes tuples by owner radix bits, then every
-         rank joins its partitions locally (radixhashjoin_amd/sharded.py).
+         rank joins its partitions locally (radixhashjoin_amd/sharded.py).  Started WITHOUT a launcher
+         (`python bench.py --gpus N`, no WORLD_SIZE in the environment) the script starts its own N ranks:
+         it runs `python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py <same args>` as a
+         CHILD process before anything here has touched the GPU, and relays rank 0's JSON line and the exit code.
 """
 import argparse
 import json
@@ -39,6 +42,38 @@ def cpu_model():
     except OSError:
         pass
     return "unknown"
+
+
+def source_blobs():
+    """git blob ids of the kernel sources (what `git hash-object` prints; computed here, the GPU box has no .git): profiles/
+    traffic.json carries the ids of the sources it was measured on, and `roofline.traffic` is only replayed from it while they
+    are the sources of the library that runs"""
+    import hashlib
+    ids = {}
+    d = os.path.join(ROOT, "radixhashjoin_amd", "csrc")
+    for f in sorted(os.listdir(d)):
+        if f.endswith((".hip", ".h")):
+            data = open(os.path.join(d, f), "rb").read()
+            ids[f] = hashlib.sha1(b"blob %d\0" % len(data) + data).hexdigest()
+    return ids
+
+
+def self_launch(args_list, gpus):
+    """`python bench.py --gpus N` without a launcher: start the N ranks ourselves.  Nothing in this process has touched the
+    GPU (torch is not even imported yet), the ranks are a child process tree, and this process only waits, relays the
+    child's output (rank 0 prints the JSON line) and returns its exit code -- never an exec over a process that holds a GPU."""
+    import socket
+    import subprocess
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + args_list
+    p = subprocess.run(cmd, env=env)
+    return p.returncode
 
 
 def np_mix(z):
@@ -253,6 +288,30 @@ def extras(eng, torch, dev, steps, which="all"):
                             "verified": (cnt, eng.pairs_checksum(out, cnt)) == exp}
     del R, S, out
 
+    # join values that defeat radix digits taken from raw low bits (multiples of 2^16 / 2^28, k * 65536 + const, dense i + 1
+    # -- SURVEY §8d's "dense variant"): the SAME PK/FK pair set re-labelled (rhj_remap_keys_dev), automatic plan, next to the
+    # uniform workload of the same size.  The engine partitions on rhj_mix64(payload) (include/rhj.h), so these cost what
+    # uniform keys cost; with raw bits (rhj_set_option "partition.mix" 0) the k << 16 case is ONE partition of 64M tuples.
+    n = 64_000_000 if which == "all" else 8_000_000
+    R = torch.empty((n, 2), dtype=torch.int64, device=dev)
+    S = torch.empty((n, 2), dtype=torch.int64, device=dev)
+    out = torch.empty((n + 1024, 2), dtype=torch.int64, device=dev)
+    leg = {}
+    for name, shift, add in (("uniform", None, 0), ("k<<16", 16, 0), ("k<<28", 28, 0), ("k*65536+const", 16, 12345), ("dense_i+1", 0, 0)):
+        eng.generate(GEN_R, R, n, D=n)
+        eng.generate(GEN_S_UNIFORM, S, n, D=n, seed=42)
+        exp = eng.expected_pkfk(S, n)                   # the pair set does not depend on how the join values are labelled
+        if shift is not None:
+            eng.remap_keys(R, n, shift, add)
+            eng.remap_keys(S, n, shift, add)
+        cnt, sec = timed_join(R, S, n, out, None, 10)
+        leg[name] = {"ms": sec * 1e3, "tuples_per_s": 2 * n / sec, "max_partition_R": eng.info("last.max_part_R"),
+                     "verified": (cnt, eng.pairs_checksum(out, cnt)) == exp}
+    for name in leg:
+        leg[name]["vs_uniform"] = leg[name]["ms"] / leg["uniform"]["ms"]
+    res[f"aligned_join_values_{n // 1_000_000}Mx{n // 1_000_000}M_auto"] = leg
+    del R, S, out
+
     # config 4: 1B x 1B Zipf(0.9) foreign key, named 8+8 plan (= the automatic plan) and 9+9
     n = 1_000_000_000
     free, _ = eng.mem_info()
@@ -368,6 +427,9 @@ def main():
     ap.add_argument("--no-auto", action="store_true", help="skip the extra (untimed-for-value) run under the automatic radix plan")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(self_launch(sys.argv[1:], args.gpus))
+
     import torch
     import radixhashjoin_amd as rhj
     from radixhashjoin_amd.binding import GEN_R, GEN_S_UNIFORM, GEN_S_ZIPF
@@ -434,6 +496,7 @@ def main():
     if world > 1:
         sj.kernel_ms = {}
     kt = {"hist": [0.0, 0], "scan": [0.0, 0], "scatter": [0.0, 0], "tasks": [0.0, 0], "join": [0.0, 0], "aux": [0.0, 0]}
+    sc_pass = {1: [0.0, 0], 2: [0.0, 0]}               # scatter launches by pass (a two-pass join: R 1, R 2, S 1, S 2)
     barrier()
     t0 = time.perf_counter()
     cnt, res = 0, None
@@ -444,6 +507,11 @@ def main():
             for k in kt:
                 kt[k][0] += t[k]["ms"]
                 kt[k][1] += t[k]["launches"]
+            sc = [ms for kind, ms in eng.launch_timings() if kind == "scatter"]
+            if args.passes == 2 and len(sc) == 4:
+                for i, ms in enumerate(sc):
+                    sc_pass[1 + (i & 1)][0] += ms
+                    sc_pass[1 + (i & 1)][1] += 1
     barrier()
     dt = time.perf_counter() - t0
     if world > 1:
@@ -471,8 +539,12 @@ def main():
         else:
             ok = (cnt == exp_cnt) and (chk == exp_chk)
     tmax = torch.tensor([dt], dtype=torch.float64, device=rdev)
+    ranks_counted = 1
     if dist is not None:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        one = torch.ones(1, dtype=torch.int64, device=rdev)        # every rank adds 1: did the collective see N ranks?
+        dist.all_reduce(one)
+        ranks_counted = int(one.item())
     dt = float(tmax.item())
 
     # N == 1 only, outside the timed region: the same workload under the engine's automatic radix plan
@@ -497,21 +569,39 @@ def main():
         ms_step = dt / args.steps * 1e3
         value = 2.0 * nglobal * args.steps / dt
         sc_ms = kt["scatter"][0] / max(kt["scatter"][1], 1)
+        sc_all_ms = sc_ms
         tuples_per_launch = n                                   # one launch scatters one relation shard once
+        # The two passes of a narrow two-pass join are two instantiations of the scatter kernel that move different bytes
+        # (pass 1: 16-byte tuples in, 12 B out; pass 2: 12 B in and out).  `roofline` prices the DOMINANT one -- pass 1, the
+        # slower -- on its own launches; the other is in `variants`.
+        by_pass = world == 1 and args.passes == 2 and sc_pass[1][1] and sc_pass[2][1]
+        if by_pass:
+            sc_ms = sc_pass[1][0] / sc_pass[1][1]
         achieved = SCATTER_BYTES_PER_TUPLE * tuples_per_launch / (sc_ms * 1e-3) / 1e9 if sc_ms else 0.0
         # format of the intermediate (rhj_get_info "last.narrow"): inside a join with a fused two-pass plan the scatter
         # writes {payload 8 B, rowID 4 B} arrays, so the bytes a launch must MOVE are fewer than SURVEY §8d's 32 B/tuple
         narrow = eng.info("last.narrow")
         moved_per_tuple = {0: 32.0, 1: (32.0 + 28.0) / 2, 2: (28.0 + 24.0) / 2}[narrow] if args.passes == 2 else 32.0
+        pass_moved = {1: {0: 32.0, 1: 32.0, 2: 28.0}[narrow], 2: {0: 32.0, 1: 28.0, 2: 24.0}[narrow]}
+        if by_pass:
+            moved_per_tuple = pass_moved[1]
         moved = moved_per_tuple * tuples_per_launch / (sc_ms * 1e-3) / 1e9 if sc_ms else 0.0
         part_ms = (kt["hist"][0] + kt["scan"][0] + kt["scatter"][0]) / args.steps
         npass_tuples = 2 * args.passes * n                      # 2 relations x passes
-        traffic = None
+        traffic, traffic_note, traffic_by_pass = None, None, {}
         tpath = os.path.join(ROOT, "profiles", "traffic.json")
         if os.path.exists(tpath):
             tj = json.load(open(tpath))
             if tj.get("tuples") == n and tj.get("bits") == [args.bits1, args.bits2] and args.passes == 2:
-                traffic = tj.get("scatter_hbm_bytes_per_launch")
+                if tj.get("source_blobs") == source_blobs():
+                    traffic_by_pass = {1: tj.get("scatter_pass1_hbm_bytes_per_launch"), 2: tj.get("scatter_pass2_hbm_bytes_per_launch")}
+                    traffic = traffic_by_pass[1] if by_pass and traffic_by_pass[1] else tj.get("scatter_hbm_bytes_per_launch")
+                    traffic_note = (f"{tj.get('source')}: two rocprofv3 --pmc passes of this command (FETCH_SIZE, WRITE_SIZE; profiles/"
+                                    "run_profile.sh), taken on the kernel sources this library was built from (blob ids match); "
+                                    "replayed, not measured by this run")
+                else:
+                    traffic_note = ("null: profiles/traffic.json was measured on other kernel sources than the ones in "
+                                    "radixhashjoin_amd/csrc now (blob ids differ) -- re-run profiles/run_profile.sh + summarize.py")
         line = {
             "metric": "join throughput (build+probe tuples/s)", "value": value, "unit": "tuples/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_step,
@@ -525,12 +615,21 @@ def main():
                                    sj.transport() + " by balanced owner class ranges, wire format " +
                                    {"narrow12": "{payload 8 B, shard-local rowID 4 B}", "tuple16": "16-byte tuples"}[sj.stats["format"]]},
             "roofline": {"bound": "hbm",
-                         "kernel": ("k_scatter_wcn" if narrow else "k_scatter_wc")
-                                   + " (line-aligned write-combining scatter-partition, one pass over one relation)",
+                         "kernel": (("k_scatter_wcn<in_narrow=false>: pass 1 of a narrow two-pass join, the dominant kernel "
+                                     "(16-byte tuples in, {payload 8 B, rowID 4 B} out)") if by_pass and narrow == 2 else
+                                    ("k_scatter_wcn" if narrow else "k_scatter_wc")
+                                    + " (line-aligned write-combining scatter-partition, one pass over one relation)"),
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": traffic,
-                         "traffic_replayed_from": "profiles/traffic.json (two rocprofv3 --pmc passes of this command, FETCH_SIZE and "
-                                                  "WRITE_SIZE, taken by profiles/run_profile.sh; not measured by this run)" if traffic else None,
+                         "traffic_replayed_from": traffic_note,
+                         "variants": {f"pass {p_}": {"avg_launch_ms": sc_pass[p_][0] / sc_pass[p_][1],
+                                                     "achieved": SCATTER_BYTES_PER_TUPLE * n / (sc_pass[p_][0] / sc_pass[p_][1] * 1e-3) / 1e9,
+                                                     "frac": SCATTER_BYTES_PER_TUPLE * n / (sc_pass[p_][0] / sc_pass[p_][1] * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                                                     "moved_bytes_per_launch": pass_moved[p_] * n,
+                                                     "achieved_moved": pass_moved[p_] * n / (sc_pass[p_][0] / sc_pass[p_][1] * 1e-3) / 1e9,
+                                                     "traffic": traffic_by_pass.get(p_)}
+                                      for p_ in (1, 2)} if by_pass else None,
+                         "avg_launch_ms_all_scatter_launches": sc_all_ms,
                          "algorithmic_bytes_per_launch": SCATTER_BYTES_PER_TUPLE * tuples_per_launch,
                          "avg_launch_ms": sc_ms,
                          "intermediate_format": {0: "16 B tuples", 1: "16 B tuples, then {payload 8 B, rowID 4 B} partitions",
@@ -551,6 +650,8 @@ def main():
                                "bytes_per_tuple_sent": {"narrow12": 12, "tuple16": 16}[sj.stats["format"]],
                                "recv_tuples_rank0": [sj.stats["recv_R"], sj.stats["recv_S"]],
                                "local_plan": sj.stats.get("plan"), "rowid_mode": sj.stats.get("rowid_mode"), "backend": dist.get_backend(),
+                               "ranks_seen": dist.get_world_size(), "ranks_in_all_reduce": ranks_counted,
+                               "devices_visible": torch.cuda.device_count(),
                                "kernel_ms_per_step_rank0": {k: v[0] / args.steps for k, v in kt.items()},
                                "kernel_ms_note": "device time of rank 0's kernels, from extra steps outside the timed region"}
         if auto is not None:

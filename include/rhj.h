@@ -120,6 +120,10 @@ int  rhj_set_option(rhj_ctx *ctx, const char *name, int64_t value);
  * an unpartitioned one), "partition.mix" (0 / 1: what joins on this context do) */
 int  rhj_get_info(rhj_ctx *ctx, const char *name, int64_t *value);
 int  rhj_get_timings(rhj_ctx *ctx, rhj_timings *out);
+/* the same per LAUNCH, in launch order: kinds[i] (rhj_kernel_kind) and ms[i] of the first min(*n, capacity) timed spans of the
+ * last call; *n = how many there were.  (A fused two-pass join scatters R pass 1, R pass 2, S pass 1, S pass 2 in that order:
+ * bench.py prices the two scatter variants separately with this.) */
+int  rhj_get_launch_timings(rhj_ctx *ctx, int32_t *kinds, double *ms, uint32_t capacity, uint32_t *n);
 int  rhj_sync(rhj_ctx *ctx);                             /* JobScheduler::barrier (JobScheduler.cpp:103-122) */
 /* pre-size / release the HBM workspace (otherwise grown on demand) */
 int  rhj_reserve(rhj_ctx *ctx, uint64_t nR, uint64_t nS, const rhj_opts *opts);

@@ -85,10 +85,17 @@ if sc:
     per_launch = sum(v["hbm_bytes_per_launch"] * v["FETCH_SIZE_launches"] for v in sc) / nl
     m = re.search(r"^(\d+) x", bench.get("config", {}).get("workload", ""))
     b = re.search(r"\((\d+)\+(\d+) bit\)", bench.get("config", {}).get("workload", ""))
+    sys.path.insert(0, ROOT)
+    from bench import source_blobs                      # the kernel sources these counters were measured on
+    def one(flag):
+        v = [x for k, x in pmc.items() if k.startswith("k_scatter_wcn<in_narrow=%s" % flag) and "hbm_bytes_per_launch" in x]
+        return v[0]["hbm_bytes_per_launch"] if len(v) == 1 else None
     json.dump({"tuples": int(m.group(1)) if m else None, "bits": [int(b.group(1)), int(b.group(2))] if b else None,
                "scatter_hbm_bytes_per_launch": per_launch,
+               "scatter_pass1_hbm_bytes_per_launch": one("false"), "scatter_pass2_hbm_bytes_per_launch": one("true"),
                "kernels": sorted(k for k in pmc if k.startswith("k_scatter_wc")),
-               "source": f"profiles/{rnd}_{tag}_pmc.json"}, open(os.path.join(ROOT, "profiles", "traffic.json"), "w"), indent=1)
+               "source": f"profiles/{rnd}_{tag}_pmc.json", "source_blobs": source_blobs()},
+              open(os.path.join(ROOT, "profiles", "traffic.json"), "w"), indent=1)
 for r in rows[:8]:
     print(f'{short(r["Name"]):40s} calls={r["Calls"]:>4s} avg={float(r["AverageNs"])/1e6:9.3f} ms  {r["Percentage"]}%')
 for k, v in pmc.items():

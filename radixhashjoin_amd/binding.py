@@ -59,6 +59,7 @@ SYMBOLS = {
     "rhj_set_option": (C.c_int, [_vp, C.c_char_p, C.c_int64]),
     "rhj_get_info": (C.c_int, [_vp, C.c_char_p, C.POINTER(C.c_int64)]),
     "rhj_get_timings": (C.c_int, [_vp, _P(Timings)]),
+    "rhj_get_launch_timings": (C.c_int, [_vp, _P(_i32), _P(C.c_double), C.c_uint32, _P(C.c_uint32)]),
     "rhj_sync": (C.c_int, [_vp]),
     "rhj_reserve": (C.c_int, [_vp, _u64, _u64, _P(Opts)]),
     "rhj_release_workspace": (C.c_int, [_vp]),
@@ -275,6 +276,12 @@ class Engine:
         t = Timings()
         self._chk(self.lib.rhj_get_timings(self.ctx, C.byref(t)))
         return t.as_dict()
+
+    def launch_timings(self, capacity=256):
+        """[(kind name, ms)] of every timed launch span of the last call, in launch order (profiling must be on)"""
+        kinds, ms, n = (_i32 * capacity)(), (C.c_double * capacity)(), C.c_uint32()
+        self._chk(self.lib.rhj_get_launch_timings(self.ctx, kinds, ms, capacity, C.byref(n)))
+        return [(KERNEL_KINDS[kinds[i]], ms[i]) for i in range(min(n.value, capacity))]
 
     def sync(self):
         self._chk(self.lib.rhj_sync(self.ctx))

@@ -1146,6 +1146,22 @@ int rhj_get_timings(rhj_ctx *ctx, rhj_timings *out)
     return RHJ_OK;
 }
 
+int rhj_get_launch_timings(rhj_ctx *ctx, int32_t *kinds, double *ms, uint32_t capacity, uint32_t *n)
+{
+    if (!ctx || !n || (capacity && (!kinds || !ms))) return RHJ_E_INVALID;
+    RHJCHK(use_device(ctx));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    Prof &p = ctx->prof;
+    *n = (uint32_t)p.used;
+    for (size_t i = 0; i < p.used && i < capacity; i++) {
+        float t = 0;
+        if (hipEventElapsedTime(&t, p.pool[2 * i], p.pool[2 * i + 1]) != hipSuccess) { (void)hipGetLastError(); t = 0; }
+        kinds[i] = p.kinds[i];
+        ms[i] = t;
+    }
+    return RHJ_OK;
+}
+
 int rhj_sync(rhj_ctx *ctx)
 {
     RHJCHK(use_device(ctx));

@@ -36,6 +36,12 @@ def test_reduced_run_prints_one_json_line():
     for k in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
         assert k in r
     assert r["bound"] == "hbm" and r["peak"] == 8000.0 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9
+    # the two scatter variants of a two-pass join are priced separately; `roofline` itself is the dominant one (pass 1)
+    v = r["variants"]
+    assert set(v) == {"pass 1", "pass 2"} and abs(v["pass 1"]["achieved"] - r["achieved"]) < 1e-6
+    assert r["avg_launch_ms"] == v["pass 1"]["avg_launch_ms"]
+    # no traffic figure unless profiles/traffic.json was measured on this size AND on these kernel sources
+    assert r["traffic"] is None
     c = d["cpu_baseline"]
     for k in ("value", "unit", "cores", "kind", "sample"):
         assert k in c

@@ -56,3 +56,24 @@ def test_bench_multirank_gloo_rehearsal(ranks, dist_, tuples, tmp_path):
     # balanced class ranges: rank 0 receives about its share even with a Zipf foreign key
     assert sum(sh["recv_tuples_rank0"]) <= 1.3 * 2 * tuples
     assert sh["kernel_ms_per_step_rank0"]["join"] > 0 and sh["kernel_ms_per_step_rank0"]["scatter"] > 0
+    assert sh["ranks_seen"] == ranks and sh["ranks_in_all_reduce"] == ranks      # the collectives really spanned N ranks
+
+
+def test_bench_starts_its_own_ranks(tmp_path):
+    """`python bench.py --gpus 2` with NO launcher and no WORLD_SIZE in the environment (how a driver without torchrun calls
+    it): the script starts torch.distributed.run as a child before touching the GPU and relays rank 0's line and the rc"""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    env.update(RHJ_BENCH_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--tuples", "3000000",
+           "--cpu-sample", "0", "--no-extras"]
+    err = open(tmp_path / "stderr.txt", "wb")
+    r = subprocess.run(cmd, cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=err, timeout=900)
+    err.close()
+    assert r.returncode == 0, open(tmp_path / "stderr.txt", "rb").read()[-3000:].decode(errors="replace")
+    lines = [ln for ln in r.stdout.decode().splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    line = json.loads(lines[0])
+    assert line["verified"] is True and line["n_gpus"] == 2 and line["sharded"]["ranks_seen"] == 2
+    # a failing child's exit code comes back: an impossible plan makes every rank exit non-zero
+    bad = subprocess.run(cmd + ["--bits1", "99"], cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, timeout=900)
+    assert bad.returncode != 0

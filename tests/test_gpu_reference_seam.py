@@ -77,25 +77,18 @@ def run_once(path, stdin, log, limit):
 
 
 def run_binary(path, stdin, log, limit):
-    """join_seam and join_optB contain the reference's JobScheduler unchanged, and its stop() (JobScheduler.cpp:140-146) sets
-    `done` and broadcasts WITHOUT holding queueLock: a worker that has just tested `!done` under the lock and not yet reached
-    pthread_cond_wait misses the only wake-up and pthread_join never returns.  Behind the GPU seam the inner workers of every
-    query thread are idle from start to stop, which is exactly that window.  One full GPU run of this suite stopped for good
-    in the edge-query test (a second of work); oracle/ref_sched_race.cpp reproduces the stall with the reference's files
-    alone.  So a child that outlives its limit is killed -- the failure message names what each of its threads was blocked
-    in -- and run again ONCE; join_optA (this repo's scheduler, which publishes `done` under the lock and passes
-    host/sched_stress) gets no second run."""
+    """One run, no second chance: a child that outlives its limit fails the test, and the message names what each of its
+    threads was blocked in.  (Round 3 re-ran join_seam / join_optB once, because the reference's JobScheduler::stop --
+    JobScheduler.cpp:140-146 -- sets `done` and broadcasts without queueLock and an idle worker can sleep through the only
+    wake-up; behind the GPU seam the inner workers are idle from init to stop.  Both binaries now carry the two-line fix
+    INTEGRATION.md gives with Option B -- join_optB as the source edit a maintainer makes, tools/bind_reference.sh; join_seam,
+    which edits nothing, by binding JobScheduler::stop at link time next to the seam itself, oracle/ref_gpu_seam.cpp -- and
+    oracle/_ref/sched_race_fixed loops init / stop / destroy over that stop() 6 x 10^5 times where the reference's own stalls
+    within 10^5, tests/test_integration_build.py.  join_optA holds this repo's scheduler.)"""
     try:
         return run_once(path, stdin, log, limit)
-    except ChildTimeout as first:
-        if os.path.basename(path) == "join_optA":
-            pytest.fail(str(first))
-        if os.path.exists(log) and str(log) != os.devnull:
-            os.remove(log)
-        try:
-            return run_once(path, stdin, log, limit)
-        except ChildTimeout as second:
-            pytest.fail(f"twice: {first} | {second}")
+    except ChildTimeout as e:
+        pytest.fail(str(e))
 
 
 def test_reference_code_drives_gpu_join(tmp_path, small_joins):

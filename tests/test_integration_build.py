@@ -61,6 +61,24 @@ def test_seam_target_builds():
     assert "Query::run_joins" in d
 
 
+def test_bound_binaries_carry_the_fixed_stop(tmp_path):
+    """join_seam binds JobScheduler::stop next to the seam (the reference's racy body stays under another name, uncalled);
+    Option B's copy of JobScheduler.cpp gets the two-line source edit and nothing else; and the start / stop loop over the
+    fixed stop() gets through 2 x 10^5 cycles (the reference's own stalls within 10^5 here: `make -C oracle _ref/sched_race`)"""
+    seam = os.path.join(ROOT, "oracle", "_ref", "join_seam")
+    d = _defined_symbols(seam)
+    assert "JobScheduler::stop()" in d and "JobScheduler::ref_stop_racy()" in d
+    out = tmp_path / "optB"
+    r = subprocess.run([TOOL, "B", REF, str(out)], capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout + r.stderr
+    diff = subprocess.run(["diff", os.path.join(REF, "JobScheduler.cpp"), str(out / "JobScheduler.cpp")], capture_output=True, text=True).stdout
+    changed = [ln for ln in diff.splitlines() if ln[:1] in "<>"]
+    assert changed == [">     pthread_mutex_lock(&queueLock);", ">     pthread_mutex_unlock(&queueLock);"], diff
+    loop = os.path.join(ROOT, "oracle", "_ref", "sched_race_fixed")
+    r = subprocess.run([loop, "200000"], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and r.stdout.strip().endswith("completed")
+
+
 def test_cpp_sharded_host_links_rccl_and_the_shard_stage_calls():
     """radixhashjoin_amd/host/sharded_host.cpp: the multi-GPU schedule from a C++ host -- RCCL for the collectives, the
     C-ABI for the compute (no torch, no Python)"""

@@ -28,8 +28,14 @@ A)  # Option A: swap three translation units for the mirror (radixhashjoin_amd/h
     $CXX $FLAGS -I"$host" -I"$here/include" *.cpp "$host/librhj_compat.a" \
         -L"$here/radixhashjoin_amd" -lrhj_hip -Wl,-rpath,"$here/radixhashjoin_amd" -Wl,-rpath,'$ORIGIN/../../radixhashjoin_amd' -o join
     ;;
-B)  # Option B: every reference file kept; only the body of the seam (Result.cpp:90-124) is replaced
+B)  # Option B: every reference file kept; only the body of the seam (Result.cpp:90-124) is replaced ...
     { sed -n '1,89p' "$ref/Result.cpp"; cat "$host/binding_option_b.inc"; sed -n '125,$p' "$ref/Result.cpp"; } > Result.cpp
+    # ... and the two-line fix of JobScheduler::stop that INTEGRATION.md gives with Option B: `done` is published under
+    # queueLock (as shipped -- JobScheduler.cpp:140-146 -- an idle worker can miss the only wake-up, and behind the GPU seam
+    # the inner workers are idle from init to stop)
+    grep -q '^void JobScheduler::stop() {$' JobScheduler.cpp && grep -q '^    done = true;$' JobScheduler.cpp
+    sed -i '/^void JobScheduler::stop() {$/,/^}$/{s/^    done = true;$/    pthread_mutex_lock(\&queueLock);\n    done = true;/; s/^    pthread_cond_broadcast(&cond_nonempty);$/    pthread_cond_broadcast(\&cond_nonempty);\n    pthread_mutex_unlock(\&queueLock);/}' JobScheduler.cpp
+    [ "$(grep -c 'pthread_mutex_unlock(&queueLock);$' JobScheduler.cpp)" = 1 ]       # exactly the one line added, inside stop()
     $CXX $FLAGS -I"$here/include" *.cpp -L"$here/radixhashjoin_amd" -lrhj_hip \
         -Wl,-rpath,"$here/radixhashjoin_amd" -Wl,-rpath,'$ORIGIN/../../radixhashjoin_amd' -o join
     ;;

@@ -40,7 +40,8 @@ class Oracle:
 
     def __init__(self):
         build()
-        self.lib = L = C.CDLL(os.path.join(HERE, "liborc.so"))
+        # RHJ_ORACLE_LIB: another build of the same source (`make -C oracle asan` runs the oracle's tests over liborc_asan.so)
+        self.lib = L = C.CDLL(os.environ.get("RHJ_ORACLE_LIB") or os.path.join(HERE, "liborc.so"))
         L.orc_next_prime.restype = _sz
         L.orc_next_prime.argtypes = [_sz]
         L.orc_mix.restype = _u64

@@ -199,10 +199,8 @@ void release(DevBuf &b)
     b.cap = 0;
 }
 
-void stager_destroy(rhj_ctx *ctx)
+void stager_free(Stager *st)
 {
-    Stager *st = ctx->stager;
-    if (!st) return;
     {
         std::lock_guard<std::mutex> lk(st->mu);
         st->quit = true;
@@ -214,7 +212,37 @@ void stager_destroy(rhj_ctx *ctx)
         if (st->ev[i]) (void)hipEventDestroy(st->ev[i]);
     }
     delete st;
+}
+
+void stager_destroy(rhj_ctx *ctx)
+{
+    if (ctx->stager) stager_free(ctx->stager);
     ctx->stager = nullptr;
+}
+
+// Built completely before the context sees it: a stager with fewer than STAGE_WORKERS workers would leave h2d_staged
+// waiting for chunks nobody fills.  Null when a pinned buffer, an event or a thread cannot be had (the caller then copies
+// straight from the pageable source).
+Stager *stager_create(int device)
+{
+    Stager *st = new (std::nothrow) Stager();
+    if (!st) return nullptr;
+    st->device = device;
+    bool ok = true;
+    for (int i = 0; i < STAGE_BUFS && ok; i++)
+        ok = hipHostMalloc(&st->buf[i], STAGE_BYTES, hipHostMallocDefault) == hipSuccess &&
+             hipEventCreateWithFlags(&st->ev[i], hipEventDisableTiming) == hipSuccess;
+    try {
+        for (int i = 0; i < STAGE_WORKERS && ok; i++) st->workers.emplace_back([st] { st->work(); });
+    } catch (...) {                                        // std::system_error: no more threads -- never through the C ABI
+        ok = false;
+    }
+    if (!ok) {
+        (void)hipGetLastError();
+        stager_free(st);
+        return nullptr;
+    }
+    return st;
 }
 
 // asynchronous with respect to the device: returns when the last chunk's DMA has been ENQUEUED on `stream` (the source has
@@ -225,15 +253,10 @@ int h2d_staged(rhj_ctx *ctx, void *d_dst, const void *src, size_t bytes, hipStre
         HIPCHK(ctx, hipMemcpyAsync(d_dst, src, bytes, hipMemcpyHostToDevice, stream));
         return RHJ_OK;
     }
-    if (!ctx->stager) {
-        Stager *st = new Stager();
-        st->device = ctx->device;
-        ctx->stager = st;
-        for (int i = 0; i < STAGE_BUFS; i++) {
-            HIPCHK(ctx, hipHostMalloc(&st->buf[i], STAGE_BYTES, hipHostMallocDefault));
-            HIPCHK(ctx, hipEventCreateWithFlags(&st->ev[i], hipEventDisableTiming));
-        }
-        for (int i = 0; i < STAGE_WORKERS; i++) st->workers.emplace_back([st] { st->work(); });
+    if (!ctx->stager) ctx->stager = stager_create(ctx->device);
+    if (!ctx->stager) {                                                   // no pinned ring to be had: the plain (slower) copy
+        HIPCHK(ctx, hipMemcpyAsync(d_dst, src, bytes, hipMemcpyHostToDevice, stream));
+        return RHJ_OK;
     }
     Stager *st = ctx->stager;
     const size_t nchunks = (bytes + STAGE_BYTES - 1) / STAGE_BYTES;
@@ -918,6 +941,18 @@ int join_phase(rhj_ctx *ctx, void *d_out, u64 cap, u64 *out_count)
                          ctx->cur_nparts, ctx->cur_radix_bits, ctx->cur_probe_split, d_out, cap, out_count, ctx->cur_narrow != 0);
 }
 
+// bookkeeping of the narrow-format back-off (rhj.h "partition.narrow"), shared by the plain and the pipelined host path
+void narrow_note_fallback(rhj_ctx *ctx)                  // a join met a rowID >= 2^32 in the narrow format
+{
+    ctx->narrow_fail_streak++;
+    ctx->narrow_skip = ctx->narrow_fail_streak < 2 ? 0u : (ctx->narrow_fail_streak > 5 ? 32u : 1u << (ctx->narrow_fail_streak - 1));
+}
+void narrow_note_done(rhj_ctx *ctx, const rhj_opts &plan, bool tried_narrow)   // a join ran to its end in one format
+{
+    if (tried_narrow) ctx->narrow_fail_streak = 0;
+    else if (ctx->narrow_skip > 0 && plan.passes == 2) ctx->narrow_skip--;
+}
+
 // partition + join.  A run in the narrow format whose histogram kernel met a rowID >= 2^32 costs two histogram launches
 // (every later kernel of the run returns at once) and is repeated in the 16-byte format; the fall-back is per join.
 int partition_and_join(rhj_ctx *ctx, const void *d_R, u64 nR, const void *d_S, u64 nS, const rhj_opts &plan, void *d_out,
@@ -926,14 +961,12 @@ int partition_and_join(rhj_ctx *ctx, const void *d_R, u64 nR, const void *d_S, u
     int rc = partition_phase(ctx, d_R, nR, d_S, nS, plan, before_S);
     if (rc != RHJ_OK) { ctx->counters_clean = false; return rc; }
     const bool tried_narrow = ctx->cur_narrow != 0;
-    if (!tried_narrow && ctx->narrow_skip > 0 && plan.passes == 2) ctx->narrow_skip--;
     rc = join_phase(ctx, d_out, cap, out_count);
     if (rc != RHJ_RETRY_WIDE) {
-        if (rc == RHJ_OK && tried_narrow) ctx->narrow_fail_streak = 0;
+        if (rc == RHJ_OK && !ctx->narrow_off_once) narrow_note_done(ctx, plan, tried_narrow);   // (off_once: the repeat of a join that fell back)
         return rc;
     }
-    ctx->narrow_fail_streak++;
-    ctx->narrow_skip = ctx->narrow_fail_streak < 2 ? 0u : (ctx->narrow_fail_streak > 5 ? 32u : 1u << (ctx->narrow_fail_streak - 1));
+    narrow_note_fallback(ctx);
     ctx->narrow_off_once = true;
     rc = partition_phase(ctx, d_R, nR, d_S, nS, plan);
     ctx->narrow_off_once = false;
@@ -1338,6 +1371,7 @@ namespace {
 // ranges of pairs home into the result page.  Returns RHJ_NOT_PIPELINED when the call should take the plain path instead
 // (small inputs, a rowID that does not fit the narrow format, more pairs than the optimistic page holds).
 constexpr int RHJ_NOT_PIPELINED = 1001;
+constexpr int RHJ_NOT_PIPELINED_WIDE = 1002;           // ... because a rowID did not fit the narrow format: the repeat runs 16-byte
 constexpr u64 PIPE_MIN_CHUNK = (u64)8 << 20;           // tuples per S chunk at least
 constexpr int PIPE_MAX_CHUNKS = 16;
 
@@ -1347,8 +1381,9 @@ int join_host_pipelined(rhj_ctx *ctx, const rhj_tuple *R, u64 nR, const rhj_tupl
     static const bool off = getenv("RHJ_NO_PIPELINE") != nullptr;                 // tuning aid: A/B against the plain path
     static const bool trace = getenv("RHJ_TRACE_JOIN") != nullptr;
     static const u64 max_chunks = env_u64("RHJ_PIPE_CHUNKS", 12, 2, PIPE_MAX_CHUNKS);   // tuning aid
-    int K = (int)(nS / PIPE_MIN_CHUNK < max_chunks ? nS / PIPE_MIN_CHUNK : max_chunks);
-    if (off || plan.passes < 1 || nS < 4 * PIPE_MIN_CHUNK || K < 2 || nR < PIPE_MIN_CHUNK / 2) return RHJ_NOT_PIPELINED;
+    static const u64 min_chunk = env_u64("RHJ_PIPE_MIN_CHUNK", PIPE_MIN_CHUNK, 1 << 16, 1 << 26);   // (tests: pipelining at small sizes)
+    int K = (int)(nS / min_chunk < max_chunks ? nS / min_chunk : max_chunks);
+    if (off || plan.passes < 1 || nS < 4 * min_chunk || K < 2 || nR < min_chunk / 2) return RHJ_NOT_PIPELINED;
     const u64 chunk = ((nS + K - 1) / K + 4095) / 4096 * 4096;
     K = (int)((nS + chunk - 1) / chunk);
     auto now = [] { return std::chrono::steady_clock::now(); };
@@ -1423,14 +1458,14 @@ int join_host_pipelined(rhj_ctx *ctx, const rhj_tuple *R, u64 nR, const rhj_tupl
         downloader.join();
     };
 
-    bool abandon = false;                                  // wide rowID / more pairs than the page holds: take the plain path
+    bool abandon = false, saw_wide = false;                // wide rowID / more pairs than the page holds: take the plain path
     std::string errtext;
     u64 handed = 0, count = 0;
     int collected = 0;
     auto collect = [&](int j) {                            // chunk j's join has finished: hand its pairs to the downloader
         const u64 *h = (const u64 *)(ctx->h_counts + (size_t)j * 128);
         const u32 wide = *(const u32 *)(ctx->h_counts + (size_t)j * 128 + 64);
-        if (wide || h[0] > dcap) { abandon = true; return; }
+        if (wide || h[0] > dcap) { abandon = true; saw_wide = wide != 0; return; }
         if (h[5]) { errtext = "a partition's build side has " + std::to_string(h[5]) + " tuples (>= 2^32): use more radix bits"; return; }
         count = h[0];
         ctx->last.ntasks += (u32)(h[1] & 0xffffffffu);
@@ -1486,11 +1521,14 @@ int join_host_pipelined(rhj_ctx *ctx, const rhj_tuple *R, u64 nR, const rhj_tupl
         pre.page = page;                                   // (drop() frees it)
         pre.drop();
         if (rc != RHJ_OK) return rc;
+        if (abandon && saw_wide) { narrow_note_fallback(ctx); return RHJ_NOT_PIPELINED_WIDE; }
         if (abandon) return RHJ_NOT_PIPELINED;
+        narrow_note_done(ctx, plan, narrow != 0);
         *out_page = nullptr;                               // no match: head stays nullptr (Result::isEmpty)
         *out_count = 0;
         return RHJ_OK;
     }
+    narrow_note_done(ctx, plan, narrow != 0);
     pre.page = nullptr;                                    // the caller's now
     ctx->last_pipelined = K;
     memset(page, 0, 8);                                    // bucket_info::next = nullptr (Result.h:14-17)
@@ -1522,9 +1560,13 @@ int rhj_join(rhj_ctx *ctx, const rhj_tuple *R, uint64_t nR, const rhj_tuple *S, 
     if (plan.passes == 0 && is_direct(ctx, 1, nR, nS)) return join_small_host(ctx, R, nR, S, nS, out_page, (u64 *)out_count);
     {
         const int prc = join_host_pipelined(ctx, R, nR, S, nS, plan, out_page, (u64 *)out_count);
-        if (prc != RHJ_NOT_PIPELINED) return prc;
+        if (prc != RHJ_NOT_PIPELINED && prc != RHJ_NOT_PIPELINED_WIDE) return prc;
         prof_reset(ctx);
+        if (prc == RHJ_NOT_PIPELINED_WIDE) {                // the pipelined attempt has met a wide rowID (and recorded it): the
+            ctx->narrow_off_once = true;                    // plain path below goes straight to 16-byte tuples
+        }
     }
+    struct OffOnce { rhj_ctx *c; ~OffOnce() { c->narrow_off_once = false; } } off_once{ctx};
     // optimistic capacity: a foreign-key join yields about max(|R|,|S|) pairs; the count is exact
     // either way, and an overflow only repeats the join phase (partitions stay in the workspace)
     u64 cap = (nR > nS ? nR : nS) + 1024;

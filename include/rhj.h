@@ -227,7 +227,9 @@ int rhj_shard_plan(uint64_t nR, uint64_t nS, const rhj_opts *in, rhj_opts *resol
 int rhj_shard_stats(rhj_ctx *ctx, int side, const rhj_tuple *d_rel, uint64_t n, int shift, int bits, uint64_t *hist,
                     uint64_t *key_min, uint64_t *key_max);
 /* asynchronous; d_narrow_out has rhj_narrow_bytes(n) bytes; d_class_start (device, 2^bits + 1, may be NULL) gets the class
- * boundaries inside the output.  Same d_rel / n / shift / bits as the rhj_shard_stats call of this side. */
+ * boundaries inside the output.  Same d_rel / n / shift / bits as the rhj_shard_stats call of this side (key_base is checked
+ * against the rowID range that call found; a different relation whose rowIDs do not fit is detected on the device and
+ * reported by the rhj_shard_join of this context: RHJ_E_INVALID). */
 int rhj_shard_split(rhj_ctx *ctx, int side, const rhj_tuple *d_rel, uint64_t n, int shift, int bits, uint64_t key_base,
                     void *d_narrow_out, uint64_t *d_class_start);
 /* asynchronous; seg_off: HOST array of nseg + 1 offsets into the received arrays (seg_off[0] = 0, seg_off[nseg] = m),

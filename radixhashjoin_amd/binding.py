@@ -163,8 +163,10 @@ SHARD_TAGGED, SHARD_GLOBAL16, SHARD_PLAIN = 1, 2, 3      # include/rhj.h: how th
 
 
 def shard_plan(nR, nS, opts=None):
-    """(mode, plan): mode = SHARD_TAGGED / SHARD_GLOBAL16 when the narrow sharded path (rhj_shard_*) serves a local join of
-    these sizes under `plan`, 0 when it does not (exchange 16-byte tuples instead)"""
+    """(mode, plan): mode = SHARD_TAGGED / SHARD_GLOBAL16 (or SHARD_PLAIN for the 17-18-bit local plans of receivers beyond
+    1.1 * 10^9 tuples, which cannot restore rowIDs) when the narrow sharded path (rhj_shard_*) serves a local join of these sizes
+    under `plan`, 0 when it does not (exchange 16-byte tuples instead).  The host may use SHARD_PLAIN instead of the other two
+    whenever every rowID of both relations is below 2^32."""
     lib = load_library()
     out = Opts()
     rc = lib.rhj_shard_plan(nR, nS, C.byref(opts) if opts is not None else None, C.byref(out))

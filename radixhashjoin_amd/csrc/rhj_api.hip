@@ -109,6 +109,7 @@ struct rhj_ctx {
     bool small_hdr_clean = false;      // the header has been zeroed behind the previous small join
     DevBuf hist_tmp, scan_tmp, hist2, grp_rng, unit_start2, seg_rng, tag_base;
     DevBuf shard_ps[2], shard_mm;      // multi-GPU sender: class boundaries per side, rowID {min, max} per side
+    DevBuf shard_wide;                 // u32 per side: rhj_shard_split met a rowID - key_base >= 2^32 (checked by rhj_shard_join)
     // rhj_dev_alloc / rhj_dev_free keep released blocks for re-use (all work of a context is ordered on its one
     // stream, so a block may be handed out again while kernels that used it are still queued): a device-resident
     // query allocates and frees a dozen arrays per join, and hipMalloc/hipFree would synchronise every time
@@ -1080,7 +1081,7 @@ int rhj_release_workspace(rhj_ctx *ctx)
                      &ctx->unit_start_b, &ctx->unit_hist_b, &ctx->unit_base_b, &ctx->scan_tmp_b, &ctx->tasks,
                      &ctx->counters, &ctx->out_pairs, &ctx->small_out, &ctx->hist_tmp, &ctx->scan_tmp, &ctx->hist2,
                      &ctx->grp_rng, &ctx->unit_start2, &ctx->narrow_flag, &ctx->seg_rng, &ctx->tag_base,
-                     &ctx->shard_ps[0], &ctx->shard_ps[1], &ctx->shard_mm};
+                     &ctx->shard_ps[0], &ctx->shard_ps[1], &ctx->shard_mm, &ctx->shard_wide};
     for (DevBuf *b : all) release(*b);
     ctx->small_hdr_clean = false;
     for (auto &b : ctx->free_blocks) {
@@ -1818,6 +1819,8 @@ int rhj_shard_stats(rhj_ctx *ctx, int side, const rhj_tuple *d_rel, uint64_t n, 
     RHJCHK(ensure(ctx, *t.scan_tmp, scan_tmp_bytes(bits)));
     RHJCHK(ensure(ctx, ctx->shard_ps[side], (nbins + 1) * 8));
     RHJCHK(ensure(ctx, ctx->shard_mm, 64));
+    RHJCHK(ensure(ctx, ctx->shard_wide, 64));
+    HIPCHK(ctx, hipMemsetAsync((u32 *)ctx->shard_wide.p + side, 0, 4, ctx->stream));
     u64 *mm = (u64 *)ctx->shard_mm.p + 2 * side;
     const u64 init[2] = {~0ull, 0ull};
     {
@@ -1865,15 +1868,13 @@ int rhj_shard_split(rhj_ctx *ctx, int side, const rhj_tuple *d_rel, uint64_t n, 
     const ShardTables t = shard_tables(ctx, side);
     PassGeom g = make_geom(n, 1, shift, bits);
     g.mix = MIX_STORE;                                   // the wire carries mix64(payload); the receiver never mixes again
-    RHJCHK(ensure(ctx, ctx->narrow_flag, 64));
     {
-        Span s(ctx, RHJ_K_AUX);
-        HIPCHK(ctx, hipMemsetAsync(ctx->narrow_flag.p, 0, 64, ctx->stream));
-    }
-    {
+        // the range check above holds for the relation rhj_shard_stats saw; a DIFFERENT relation handed in here may still hold a
+        // rowID whose offset from key_base does not fit 32 bits: the kernel raises this side's word of shard_wide (cleared by
+        // rhj_shard_stats) and rhj_shard_join of this context reports it
         Span s(ctx, RHJ_K_SCATTER);
         launch_scatter_units_narrow(ctx->stream, d_rel, d_narrow_out, n, g, (const u64 *)t.seg0->p, (const u32 *)t.unit_start->p,
-                                    (const u64 *)t.unit_base->p, (u32 *)ctx->narrow_flag.p, key_base);
+                                    (const u64 *)t.unit_base->p, (u32 *)ctx->shard_wide.p + side, key_base);
     }
     if (d_class_start)
         HIPCHK(ctx, hipMemcpyAsync(d_class_start, ctx->shard_ps[side].p, (nbins + 1) * 8, hipMemcpyDeviceToDevice, ctx->stream));
@@ -1960,6 +1961,13 @@ int rhj_shard_join(rhj_ctx *ctx, rhj_pair *d_out, uint64_t out_capacity, uint64_
                            mode == RHJ_SHARD_TAGGED ? (const u64 *)ctx->tag_base.p : nullptr, false);
     if (rc == RHJ_RETRY_WIDE) return fail(ctx, RHJ_E_HIP, "rhj_shard_join: unexpected wide-rowID flag");
     RHJCHK(rc);
+    if (ctx->shard_wide.p) {                               // what this context's own rhj_shard_split calls met (the stream is idle here)
+        u32 w[2] = {0, 0};
+        HIPCHK(ctx, hipMemcpy(w, ctx->shard_wide.p, 8, hipMemcpyDeviceToHost));
+        if (w[0] | w[1])
+            return fail(ctx, RHJ_E_INVALID, "rhj_shard_split: a rowID - key_base did not fit 32 bits -- the relation differs from the "
+                                            "one given to rhj_shard_stats for that side; what was sent is incomplete");
+    }
     if (d_out && *out_count > out_capacity) return fail(ctx, RHJ_E_OVERFLOW, "result buffer too small");
     return RHJ_OK;
 }

@@ -26,8 +26,18 @@
 #define NCCLOK(x) do { ncclResult_t r_ = (x); if (r_ != ncclSuccess) { fprintf(stderr, "%s: %s\n", #x, ncclGetErrorString(r_)); exit(2); } } while (0)
 #define RHJOK(ctx, x) do { int r_ = (x); if (r_ != RHJ_OK) { fprintf(stderr, "%s: %s\n", #x, rhj_last_error(ctx)); exit(2); } } while (0)
 
-static const int SHIFT = 20, BITS = 8, C = 1 << BITS;        // owner classes: payload bits [20, 28)
-static const uint64_t MAX_MSG = (uint64_t)64 << 20;           // tuples per RCCL message at most
+static const int SHIFT = 20, BITS = 8, C = 1 << BITS;        // owner classes: bits [20, 28) of rhj_mix64(payload)
+// tuples per RCCL message at most (512 MiB of payloads).  Test knobs, mirroring sharded.py's max_msg_bytes / force_exchange:
+//   RHJ_SHARD_MAX_MSG=<tuples>   smaller messages, so that the piece loop and RCCL's in-order matching of several sends to one
+//                                peer run at test sizes
+//   RHJ_SHARD_VIA_SELF=1         the rank's OWN segment goes through ncclSend / ncclRecv too, in pieces like a peer's -- the
+//                                only way a one-GPU box can execute the send / receive loop at all (world > 1 over RCCL needs
+//                                one GPU per rank; unverified on this pool)
+static uint64_t env_u64(const char *name, uint64_t dflt)
+{
+    const char *v = getenv(name);
+    return v && *v ? strtoull(v, nullptr, 10) : dflt;
+}
 
 // contiguous class ranges of near-equal weight (every rank computes the same cuts from the same gathered histogram)
 static std::vector<int> balanced_cuts(const std::vector<uint64_t> &w, int world)
@@ -55,6 +65,10 @@ int main(int argc, char **argv)
     const uint64_t n = argc > 4 ? strtoull(argv[4], nullptr, 10) : 4000000;
     const bool zipf = argc > 5 && !strcmp(argv[5], "zipf");
     if (world < 1 || world > 16 || rank < 0 || rank >= world) { fprintf(stderr, "1 <= world <= 16\n"); return 1; }
+    const uint64_t MAX_MSG = env_u64("RHJ_SHARD_MAX_MSG", (uint64_t)64 << 20);
+    const bool via_self = env_u64("RHJ_SHARD_VIA_SELF", 0) != 0;
+    if (MAX_MSG == 0) { fprintf(stderr, "RHJ_SHARD_MAX_MSG must be positive\n"); return 1; }
+    uint64_t messages = 0;                                // ncclSend calls issued by this rank
     int ndev = 0;
     HIPOK(hipGetDeviceCount(&ndev));
     const int device = rank % ndev;
@@ -160,7 +174,7 @@ int main(int argc, char **argv)
         NCCLOK(ncclGroupStart());
         uint64_t soff = 0;
         for (int d = 0; d < world; d++) {
-            if (d == rank) {
+            if (d == rank && !via_self) {
                 HIPOK(hipMemcpyAsync((uint64_t *)rP[rel] + seg[rel][d], sP + soff, send[rel][d] * 8, hipMemcpyDeviceToDevice, st));
                 HIPOK(hipMemcpyAsync((uint32_t *)rK[rel] + seg[rel][d], sK + soff, send[rel][d] * 4, hipMemcpyDeviceToDevice, st));
             } else {
@@ -170,6 +184,7 @@ int main(int argc, char **argv)
                     const uint64_t c = send[rel][d] - o < MAX_MSG ? send[rel][d] - o : MAX_MSG;
                     NCCLOK(ncclSend(sP + soff + o, c, ncclUint64, d, comm, st));
                     NCCLOK(ncclSend(sK + soff + o, c, ncclUint32, d, comm, st));
+                    messages += 2;
                 }
                 for (uint64_t o = 0; o < recv[rel][d]; o += MAX_MSG) {
                     const uint64_t c = recv[rel][d] - o < MAX_MSG ? recv[rel][d] - o : MAX_MSG;
@@ -206,9 +221,11 @@ int main(int argc, char **argv)
     const bool ok = tot[0] == tot[1] && tot[2] == tot[3];
     if (rank == 0)
         printf("{\"world\": %d, \"rows_per_rank\": %llu, \"dist\": \"%s\", \"wire_bytes_per_tuple\": 12, \"rowid_mode\": %d, "
-               "\"plan\": [%d, %d, %d], \"pairs_global\": %llu, \"ms_first_join\": %.2f, \"verified\": %s}\n",
+               "\"plan\": [%d, %d, %d], \"pairs_global\": %llu, \"ms_first_join\": %.2f, \"own_segment\": \"%s\", "
+               "\"nccl_sends_rank0\": %llu, \"max_tuples_per_message\": %llu, \"verified\": %s}\n",
                world, (unsigned long long)n, zipf ? "zipf0.9" : "uniform", mode, plan.passes, plan.bits1, plan.bits2,
-               (unsigned long long)tot[0], ms, ok ? "true" : "false");
+               (unsigned long long)tot[0], ms, via_self ? "ncclSend/ncclRecv to self" : "device copy",
+               (unsigned long long)messages, (unsigned long long)MAX_MSG, ok ? "true" : "false");
     rhj_destroy(ctx);
     NCCLOK(ncclCommDestroy(comm));
     return ok ? 0 : 4;

@@ -182,3 +182,37 @@ def test_lopsided_segments(oracle):
     a = got[np.lexsort((got[:, 1], got[:, 0]))]
     e = np.stack([exp["keyR"], exp["keyS"]], axis=1)
     assert np.array_equal(a, e[np.lexsort((e[:, 1], e[:, 0]))])
+
+
+def test_split_of_another_relation_than_stats_saw_is_reported(engine):
+    """rhj_shard_split checks key_base against the rowID range rhj_shard_stats found; a DIFFERENT relation handed to the split
+    may still hold a rowID that does not fit 32 bits from key_base: detected on the device, reported by this context's
+    rhj_shard_join (the tuples sent are incomplete)"""
+    from radixhashjoin_amd.binding import RhjError
+    rng = np.random.default_rng(5)
+    n = 40_000
+    t = np.empty(n, dtype=TUPLE)
+    t["key"] = rng.permutation(n).astype(np.uint64) + np.uint64(1000)
+    t["payload"] = rng.integers(0, 1 << 40, n).astype(np.uint64)
+    other = t.copy()
+    other["key"][1234] = np.uint64(1000 + (1 << 33))
+    mode, plan = shard_plan(n, n, Opts(2, 4, 4))
+    for bad_side in (None, 0):
+        bufs = []
+        for side in (0, 1):
+            d = engine.to_device(t)
+            hist, kmin, kmax = engine.shard_stats(side, d, n, SHIFT, BITS)
+            buf = engine.alloc(narrow_bytes(n))
+            dsplit = engine.to_device(other) if side == bad_side else d
+            engine.shard_split(side, dsplit, n, SHIFT, BITS, kmin, buf)
+            raw = buf.to_numpy(np.uint8, narrow_bytes(n))
+            bufs.append((raw[:8 * n].view(np.uint64).copy(), raw[narrow_key_offset(n):narrow_key_offset(n) + 4 * n].view(np.uint32).copy(), kmin))
+        for side, (P, K, kmin) in enumerate(bufs):
+            dP, dK = engine.to_device(P), engine.to_device(K)
+            engine.shard_partition(side, dP, dK, n, [0, n], [kmin], plan, SHARD_TAGGED)
+            engine.sync()
+        if bad_side is None:
+            assert engine.shard_join(None, 0) == n                      # (the relation joined with itself: unique payloads)
+        else:
+            with pytest.raises(RhjError, match="did not fit 32 bits"):
+                engine.shard_join(None, 0)

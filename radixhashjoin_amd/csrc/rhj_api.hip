@@ -109,6 +109,10 @@ struct rhj_ctx {
     bool small_hdr_clean = false;      // the header has been zeroed behind the previous small join
     DevBuf hist_tmp, scan_tmp, hist2, grp_rng, unit_start2, seg_rng, tag_base;
     DevBuf shard_ps[2], shard_mm;      // multi-GPU sender: class boundaries per side, rowID {min, max} per side
+    DevBuf fuse_ctl;                   // one-pass joins in three launches: global histograms, digit cursors, tickets (k_hist_fused2)
+    bool fuse_clean = false;           // ... which the kernels leave zeroed (false: the next call clears them first)
+    u64 *h_pub = nullptr, *h_pub_dev = nullptr;   // pinned: the join counters as the bucket join's last workgroup publishes them
+    int opt_fused = -1;                // -1: automatic (RHJ_FUSE env, default 1), 0 / 1
     DevBuf shard_wide;                 // u32 per side: rhj_shard_split met a rowID - key_base >= 2^32 (checked by rhj_shard_join)
     // rhj_dev_alloc / rhj_dev_free keep released blocks for re-use (all work of a context is ordered on its one
     // stream, so a block may be handed out again while kernels that used it are still queued): a device-resident
@@ -954,11 +958,118 @@ void narrow_note_done(rhj_ctx *ctx, const rhj_opts &plan, bool tried_narrow)   /
     else if (ctx->narrow_skip > 0 && plan.passes == 2) ctx->narrow_skip--;
 }
 
+// One-pass joins (plans of <= 9 bits: 2 * 10^4 ... 8 * 10^6 build tuples) in THREE launches and no device-to-host copy:
+// k_hist_fused2 (histograms of both relations; its last workgroup makes the partition boundaries, the digit cursors, the
+// join task list and clears the join counters), k_scatter_fused2 (both relations), the bucket join, whose last workgroup
+// publishes the counters to pinned host memory.  Was: unit tables, histogram, three scan launches, scatter, k_make_tasks,
+// join, a 56-byte D2H copy -- 8 dependent launches for 77 us of kernel time at 10^6 x 10^6 (BASELINE config 2).
+bool fused_one_pass_ok(const rhj_ctx *ctx, u64 nR, u64 nS, const rhj_opts &plan)
+{
+    static const int env = (int)env_u64("RHJ_FUSE", 1, 0, 1);
+    if (!(ctx->opt_fused >= 0 ? ctx->opt_fused : env)) return false;
+    return plan.passes == 1 && plan.bits1 >= 1 && plan.bits1 <= PASS_PAIR_MAX_BITS && nR > 0 && nS > 0 && nR < ((u64)1 << 32) &&
+           nS < ((u64)1 << 32);
+}
+
+int join_one_pass_fused(rhj_ctx *ctx, const void *d_R, u64 nR, const void *d_S, u64 nS, const rhj_opts &plan, void *d_out, u64 cap,
+                        u64 *out_count, std::function<int()> *before_S)
+{
+    const int bits = plan.bits1;
+    const size_t nbins = (size_t)1 << bits;
+    if (before_S && *before_S) {                             // (both relations go through the same launches: S must be there)
+        std::function<int()> f;
+        f.swap(*before_S);
+        RHJCHK(f());
+    }
+    ctx->cur_nR = nR;
+    ctx->cur_nS = nS;
+    ctx->last.passes = 1;
+    ctx->last.bits1 = bits;
+    ctx->last.bits2 = 0;
+    ctx->cur_narrow = 0;
+    ctx->counters_clean = false;
+    int kind = choose_join_kind(ctx, nR, nS, nbins, bits, false);
+    u32 probe_split = plan.probe_split ? (u32)plan.probe_split : 32768u;
+    if (join_probe_split(kind) && probe_split > join_probe_split(kind)) probe_split = join_probe_split(kind);
+    if (probe_split > BJ_MAX_PROBE_SPLIT) probe_split = BJ_MAX_PROBE_SPLIT;
+    ctx->cur_probe_split = probe_split;
+    const u64 max_tasks64 = nbins + (nR + nS) / probe_split + 1;
+    if (max_tasks64 > 0x7fffffffull) return fail(ctx, RHJ_E_INVALID, "too many join tasks");
+    const u32 max_tasks = (u32)max_tasks64;
+    PassPairHost h;
+    DevBuf *uh[2] = {&ctx->unit_hist, &ctx->unit_hist_b};
+    const void *in[2] = {d_R, d_S};
+    const u64 n[2] = {nR, nS};
+    RHJCHK(ensure(ctx, ctx->ps_R, (nbins + 1) * 8));
+    RHJCHK(ensure(ctx, ctx->ps_S, (nbins + 1) * 8));
+    RHJCHK(ensure(ctx, ctx->part_R, (size_t)nR * 16));
+    RHJCHK(ensure(ctx, ctx->part_S, (size_t)nS * 16));
+    void *out[2] = {ctx->part_R.p, ctx->part_S.p};
+    u64 *ps[2] = {(u64 *)ctx->ps_R.p, (u64 *)ctx->ps_S.p};
+    for (int i = 0; i < 2; i++) {
+        const PassGeom g = make_geom(n[i], 1, 0, bits);
+        RHJCHK(ensure(ctx, *uh[i], (size_t)g.max_units * nbins * 4));
+        h.side[i] = PassSide{in[i], out[i], nullptr, nullptr, (u32 *)uh[i]->p, nullptr, ps[i], nullptr, g};
+    }
+    h.mix = join_mix(ctx);
+    RHJCHK(ensure(ctx, ctx->tasks, (size_t)max_tasks * sizeof(JoinTask)));
+    RHJCHK(ensure(ctx, ctx->counters, 64));
+    if (ctx->fuse_ctl.cap < fuse_ctl_bytes()) { RHJCHK(ensure(ctx, ctx->fuse_ctl, fuse_ctl_bytes())); ctx->fuse_clean = false; }
+    if (!ctx->h_pub) {
+        HIPCHK(ctx, hipHostMalloc((void **)&ctx->h_pub, 64, hipHostMallocDefault));
+        if (hipHostGetDevicePointer((void **)&ctx->h_pub_dev, ctx->h_pub, 0) != hipSuccess || !ctx->h_pub_dev) {
+            (void)hipGetLastError();
+            (void)hipHostFree(ctx->h_pub);
+            ctx->h_pub = nullptr;
+            return fail(ctx, RHJ_E_HIP, "no device address for the pinned counter block");
+        }
+    }
+    if (!ctx->fuse_clean) {
+        Span s(ctx, RHJ_K_AUX);
+        HIPCHK(ctx, hipMemsetAsync(ctx->fuse_ctl.p, 0, fuse_ctl_bytes(), ctx->stream));
+    }
+    ctx->fuse_clean = false;                                 // until this call has run to its end
+    u64 *d_count = (u64 *)ctx->counters.p;
+    {
+        Span s(ctx, RHJ_K_HIST);
+        launch_fused_pass(ctx->stream, h, bits, 0, ctx->fuse_ctl.p, probe_split, max_tasks, join_table_tuples(kind), (JoinTask *)ctx->tasks.p,
+                          d_count);
+    }
+    {
+        Span s(ctx, RHJ_K_SCATTER);
+        launch_fused_pass(ctx->stream, h, bits, 1, ctx->fuse_ctl.p, 0, 0, 0, nullptr, nullptr);
+    }
+    ctx->cur_R = ctx->part_R.p;
+    ctx->cur_S = ctx->part_S.p;
+    ctx->cur_psR = ps[0];
+    ctx->cur_psS = ps[1];
+    ctx->cur_nparts = nbins;
+    ctx->cur_radix_bits = bits;
+    ctx->last_join_kind = kind;
+    volatile u64 *pub = ctx->h_pub;
+    pub[0] = ~0ull;
+    {
+        Span s(ctx, RHJ_K_JOIN);
+        launch_join(ctx->stream, ctx->cur_R, ps[0], ctx->cur_S, ps[1], (const JoinTask *)ctx->tasks.p, (const u32 *)(d_count + 1), max_tasks, bits,
+                    d_out, d_out ? cap : 0, d_count, kind, nullptr, nullptr, nullptr, nullptr, ctx->h_pub_dev, fuse_join_ticket(ctx->fuse_ctl.p));
+    }
+    RHJCHK(check_launch(ctx, "one-pass join"));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    if (pub[0] == ~0ull) return fail(ctx, RHJ_E_HIP, "the bucket join did not publish its counters");
+    ctx->fuse_clean = true;
+    *out_count = pub[0];
+    ctx->last.ntasks = (u32)(pub[1] & 0xffffffffu);
+    ctx->last_max_part[0] = pub[2];
+    ctx->last_max_part[1] = pub[3];
+    return RHJ_OK;
+}
+
 // partition + join.  A run in the narrow format whose histogram kernel met a rowID >= 2^32 costs two histogram launches
 // (every later kernel of the run returns at once) and is repeated in the 16-byte format; the fall-back is per join.
 int partition_and_join(rhj_ctx *ctx, const void *d_R, u64 nR, const void *d_S, u64 nS, const rhj_opts &plan, void *d_out,
                        u64 cap, u64 *out_count, std::function<int()> *before_S = nullptr)
 {
+    if (fused_one_pass_ok(ctx, nR, nS, plan)) return join_one_pass_fused(ctx, d_R, nR, d_S, nS, plan, d_out, cap, out_count, before_S);
     int rc = partition_phase(ctx, d_R, nR, d_S, nS, plan, before_S);
     if (rc != RHJ_OK) { ctx->counters_clean = false; return rc; }
     const bool tried_narrow = ctx->cur_narrow != 0;
@@ -1081,7 +1192,8 @@ int rhj_release_workspace(rhj_ctx *ctx)
                      &ctx->unit_start_b, &ctx->unit_hist_b, &ctx->unit_base_b, &ctx->scan_tmp_b, &ctx->tasks,
                      &ctx->counters, &ctx->out_pairs, &ctx->small_out, &ctx->hist_tmp, &ctx->scan_tmp, &ctx->hist2,
                      &ctx->grp_rng, &ctx->unit_start2, &ctx->narrow_flag, &ctx->seg_rng, &ctx->tag_base,
-                     &ctx->shard_ps[0], &ctx->shard_ps[1], &ctx->shard_mm, &ctx->shard_wide};
+                     &ctx->shard_ps[0], &ctx->shard_ps[1], &ctx->shard_mm, &ctx->shard_wide, &ctx->fuse_ctl};
+    ctx->fuse_clean = false;
     for (DevBuf *b : all) release(*b);
     ctx->small_hdr_clean = false;
     for (auto &b : ctx->free_blocks) {
@@ -1093,6 +1205,7 @@ int rhj_release_workspace(rhj_ctx *ctx)
     if (ctx->h_land) { (void)hipHostFree(ctx->h_land); ctx->h_land = nullptr; }
     stager_destroy(ctx);
     if (ctx->h_counts) { (void)hipHostFree(ctx->h_counts); ctx->h_counts = nullptr; }
+    if (ctx->h_pub) { (void)hipHostFree(ctx->h_pub); ctx->h_pub = nullptr; ctx->h_pub_dev = nullptr; }
     for (hipEvent_t e : ctx->chunk_ev) (void)hipEventDestroy(e);
     ctx->chunk_ev.clear();
     return RHJ_OK;
@@ -1134,6 +1247,7 @@ int rhj_set_option(rhj_ctx *ctx, const char *name, int64_t value)
         return RHJ_OK;
     }
     if (n == "partition.mix" && value >= -1 && value <= 1) { ctx->opt_mix = (int)value; return RHJ_OK; }
+    if (n == "join.fused" && value >= -1 && value <= 1) { ctx->opt_fused = (int)value; return RHJ_OK; }
     return fail(ctx, RHJ_E_INVALID, "rhj_set_option: unknown option or value: " + n);
 }
 

@@ -83,7 +83,7 @@ void launch_make_tasks(hipStream_t st, const u64 *d_startR, const u64 *d_startS,
 void launch_join(hipStream_t st, const void *d_R, const u64 *d_startR, const void *d_S, const u64 *d_startS,
                  const JoinTask *d_tasks, const u32 *d_ntasks, u32 grid, int radix_bits,
                  void *d_out, u64 out_capacity, u64 *d_out_count, int kind, const u32 *d_RK = nullptr, const u32 *d_SK = nullptr,
-                 const u64 *d_tag_base = nullptr, const u32 *d_skip = nullptr);
+                 const u64 *d_tag_base = nullptr, const u32 *d_skip = nullptr, u64 *host_pub = nullptr, u32 *d_done = nullptr);
 void launch_join_direct(hipStream_t st, const void *d_R, u64 nR, const void *d_S, u64 nS, void *d_out, u64 out_capacity,
                         u64 *d_out_count, u64 *host_count = nullptr, u32 *d_done = nullptr, void *host_out = nullptr,
                         u64 host_cap = 0);
@@ -105,6 +105,11 @@ struct PassSide {
 };
 struct PassPairHost { PassSide side[2]; u64 *zero8 = nullptr; /* eight 64-bit words cleared by the first launch, or null */ int mix = 0; };
 void launch_pass_pair(hipStream_t st, const PassPairHost &h, int shift, int bits, int phase);
+// one-pass joins in three launches (see k_hist_fused2): phase 0 histogram + boundaries + task list, phase 1 scatter
+size_t fuse_ctl_bytes();
+u32 *fuse_join_ticket(void *d_ctl);
+void launch_fused_pass(hipStream_t st, const PassPairHost &h, int bits, int phase, void *d_ctl, u32 probe_split, u32 max_tasks,
+                       u32 table_tuples, JoinTask *d_tasks, u64 *d_counters);
 constexpr int PASS_PAIR_MAX_BITS = 9;            // the write-combining scatter's range
 bool fused_two_pass_ok(int b1, int b2);
 // bucket-join kernels: JK_BKT partitions that fit one 4224-tuple table (two workgroups per CU); JK_BKT_BIG 8448-tuple

@@ -735,6 +735,7 @@ k_scatter_units_pipe(const Tup *__restrict__ in, Tup *__restrict__ out, const u6
 // (multi-GPU receiver) pass-2 unit u holds tuples of sender (u % ngroups) / div; see k_scatter_wcn
 struct WnTag { u32 ngroups, div, bits; };   // bits == 0: no tagging
 constexpr u32 TAG_BITS = 4, TAG_MAX = 1u << TAG_BITS;   // sender tags in the low payload bits: <= 16 ranks (== SEG_MAX)
+constexpr int FUSE_STRIDE64_FWD = 16;                                       // (= FUSE_STRIDE64, defined with the fused kernels below)
 constexpr int WC_THREADS = 1024, WC_TPT = 4;                                // geometry for 9-bit passes (tile = THREADS * WC_TPT)
 constexpr int WC_THREADS_SMALL = 512;                                       // <= 8 bits: two workgroups per CU
 constexpr int WC_MAX_BITS = 9;
@@ -747,8 +748,13 @@ __device__ __forceinline__ void
 dev_scatter_wc(const Tup *__restrict__ in, Tup *__restrict__ out, const u64 *__restrict__ seg_start,
                const u32 *__restrict__ unit_start, u32 nseg, u64 L, int shift, int bits,
                const u64 *__restrict__ unit_base, const u64 *__restrict__ unit_rng, u32 n_rng_units, const u32 u,
-               const u64 *__restrict__ inP = nullptr, const u32 *__restrict__ inK = nullptr, u64 key_add = 0, int mix = 0)
+               const u64 *__restrict__ inP = nullptr, const u32 *__restrict__ inK = nullptr, u64 key_add = 0, int mix = 0,
+               const u32 *__restrict__ hist_rows = nullptr, u64 *__restrict__ cursor = nullptr, u64 n_single = 0)
 {
+    // cursor (one-pass joins, k_scatter_fused2): no unit_base table and no scan -- the unit reserves its range of every digit
+    // with ONE atomicAdd of its histogram row (hist_rows, from k_hist_fused2) on the digit's cursor, which the histogram launch's
+    // last workgroup left at the partition's start.  Units then lie in a partition in arrival order: unspecified, like the
+    // order inside a partition has always been.  The unit is rows [u * L, (u + 1) * L) of the n_single tuples.
     // mix (16-byte input only, see MIX_* in rhj_internal.h): MIX_STORE -- first pass inside a join: the payload becomes
     // mix64(payload) as it is loaded, and that is what is written; MIX_DIGIT -- the digit comes from mix64(payload), the tuple
     // is written as it came (the multi-GPU owner split of 16-byte tuples)
@@ -772,6 +778,10 @@ dev_scatter_wc(const Tup *__restrict__ in, Tup *__restrict__ out, const u64 *__r
         if (u >= n_rng_units) return;        // the pieces of a bucket written by groups of pass-1 units)
         beg = unit_rng[u];
         end = unit_rng[u + 1];
+    } else if (cursor != nullptr) {
+        beg = (u64)u * L;
+        if (beg >= n_single) return;
+        end = (beg + L < n_single) ? beg + L : n_single;
     } else {
         if (u >= unit_start[nseg]) return;
         const u32 s = find_segment(unit_start, nseg, u);
@@ -783,7 +793,9 @@ dev_scatter_wc(const Tup *__restrict__ in, Tup *__restrict__ out, const u64 *__r
     auto dig = [&](u64 p) -> u32 { return (u32)((mix == MIX_DIGIT ? mix64(p) : p) >> shift) & mask; };
 
     for (u32 b = tid; b < nbins; b += THREADS) {
-        const u64 g = unit_base[(u64)u * nbins + b];
+        const u64 g = cursor != nullptr ? atomicAdd((unsigned long long *)&cursor[(size_t)b * FUSE_STRIDE64_FWD],
+                                                    (unsigned long long)hist_rows[(u64)u * nbins + b])
+                                        : unit_base[(u64)u * nbins + b];
         gnext[b] = g;
         LO[b] = (u32)g & 7u;
         cnt[b] = 0;
@@ -948,6 +960,165 @@ __global__ void __launch_bounds__(THREADS) k_scatter_wc2(PassPair a, int shift, 
     if (blockIdx.x >= x.max_units) return;
     dev_scatter_wc<THREADS>(x.in, x.out, x.seg_start, x.unit_start, 1u, x.L, shift, bits, x.unit_base, (const u64 *)nullptr, 0u,
                             blockIdx.x, nullptr, nullptr, 0, a.mix);
+}
+
+// ---- one-pass joins in THREE launches (mid-size joins are launch-bound: 10^6 x 10^6 was 8 dependent launches for 77 us of
+// kernel time) ------------------------------------------------------------------------------------------------------------
+//   k_hist_fused2     per-unit histograms of R and S (grid.y = relation; unit ranges computed, no unit tables), each row also
+//                     added to the relation's global histogram; the LAST workgroup to finish (ticket) turns the two global
+//                     histograms into partition boundaries and digit cursors, clears the join counters and writes the JOIN
+//                     TASK LIST (what k_init_single_segment2, three scan launches, k_make_tasks and a memset did)
+//   k_scatter_fused2  the write-combining scatter; a unit reserves its output ranges with one atomicAdd per digit (cursor)
+//   k_join_bkt        as before; its last workgroup publishes the counters to pinned host memory (no D2H copy)
+// FuseCtl lives in HBM, zero between calls: the last workgroup leaves it so (a failed call makes the host clear it).
+struct FuseCtl {
+    u32 *ghist;          // [2][512] global digit histograms of R, S
+    u64 *cursor;         // [2][512] next free slot per digit
+    u32 *ticket;         // [0]: workgroups of k_hist_fused2 that have finished
+};
+struct FuseTasks { u32 probe_split, max_tasks, table_tuples, units_per_wg; JoinTask *tasks; u64 *counters; };
+// Every counter on its own 128-byte line, the global histograms in FUSE_COPIES copies (unit u adds to copy u mod FUSE_COPIES):
+// device-scope atomics on one LINE are served one behind the other ([measured] 245 units x 256 digits x 2 relations of
+// atomics on 16 lines: 75 us for a 9 us histogram), on different lines side by side.
+constexpr int FUSE_MAX_BINS = 512, FUSE_COPIES = 4, FUSE_STRIDE32 = 32, FUSE_STRIDE64 = 16;
+static_assert(FUSE_STRIDE64 == FUSE_STRIDE64_FWD, "cursor stride");
+
+__global__ void __launch_bounds__(PART_THREADS)
+k_hist_fused2(PassPair a, int shift, int bits, FuseCtl fc, FuseTasks ft)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    u32 *cnt = reinterpret_cast<u32 *>(smem);                      // nbins
+    __shared__ u64 st[2][FUSE_MAX_BINS + 1];                       // last workgroup: partition boundaries of R, S
+    __shared__ u32 wsum[PART_THREADS / 64];
+    __shared__ u64 wmax[2][PART_THREADS / 64];
+    __shared__ u32 is_last;
+    const PassRel &x = a.r[blockIdx.y];
+    const u32 nbins = 1u << bits, mask = nbins - 1;
+    const int tid = threadIdx.x;
+    // a workgroup counts ft.units_per_wg consecutive units (a row each, for the scatter) and adds their SUM to the global
+    // histogram once: device-scope atomics are the scarce thing here ([measured] ~7 per ns over the whole chip)
+    u32 *wtot_ = cnt + nbins;                                        // this workgroup's sum over its units
+    auto dig = [&](u64 p) -> u32 { return (u32)((a.mix ? mix64(p) : p) >> shift) & mask; };
+    const u32 u0 = blockIdx.x * ft.units_per_wg;
+    if ((u64)u0 * x.L < x.n) {
+        for (u32 b = tid; b < nbins; b += PART_THREADS) wtot_[b] = 0;
+        for (u32 u = u0; u < u0 + ft.units_per_wg && (u64)u * x.L < x.n; u++) {
+            const u64 beg = (u64)u * x.L, end = (beg + x.L < x.n) ? beg + x.L : x.n;
+            for (u32 b = tid; b < nbins; b += PART_THREADS) cnt[b] = 0;
+            __syncthreads();
+            u64 i = beg + tid;
+            for (; i + 3ull * PART_THREADS < end; i += 4ull * PART_THREADS) {
+                const Tup t0 = x.in[i], t1 = x.in[i + PART_THREADS], t2 = x.in[i + 2 * PART_THREADS], t3 = x.in[i + 3 * PART_THREADS];
+                atomicAdd(&cnt[dig(t0.payload)], 1u);
+                atomicAdd(&cnt[dig(t1.payload)], 1u);
+                atomicAdd(&cnt[dig(t2.payload)], 1u);
+                atomicAdd(&cnt[dig(t3.payload)], 1u);
+            }
+            for (; i < end; i += PART_THREADS) atomicAdd(&cnt[dig(x.in[i].payload)], 1u);
+            __syncthreads();
+            u32 *row = x.unit_hist + (u64)u * nbins;
+            for (u32 b = tid; b < nbins; b += PART_THREADS) {       // (thread tid owns bins tid, tid + 512: no barrier needed for wtot_)
+                const u32 c = cnt[b];
+                row[b] = c;
+                wtot_[b] += c;
+            }
+            __syncthreads();
+        }
+        u32 *gh = fc.ghist + (size_t)(blockIdx.y * FUSE_COPIES + (blockIdx.x & (FUSE_COPIES - 1))) * FUSE_MAX_BINS * FUSE_STRIDE32;
+        u32 seen = 0;
+        for (u32 b = tid; b < nbins; b += PART_THREADS) {
+            const u32 c = wtot_[b];
+            if (c) seen += __hip_atomic_fetch_add(&gh[(size_t)b * FUSE_STRIDE32], c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        if (seen == 0xFFFFFFFFu) cnt[0] = seen;                     // (never true: keeps the atomics' return values alive)
+    }
+    // ---- ticket: the last workgroup of the launch (either relation) finishes the partition phase ---------------------
+    // No fence: the global-histogram atomics above RETURN (their values are consumed below), so they have been performed at
+    // device scope when the ticket is taken, and the last workgroup reads the histograms with device-scope atomic loads.  (A
+    // release fence here is an L2 write-back per workgroup on this multi-XCD part; the rows written above are for the NEXT
+    // launch.)
+    __syncthreads();
+    if (tid == 0) is_last = __hip_atomic_fetch_add(fc.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x * gridDim.y - 1 ? 1u : 0u;
+    __syncthreads();
+    if (!is_last) return;
+    for (int rel = 0; rel < 2; rel++) {
+        const PassRel &y = a.r[rel];
+        u32 c = 0;
+        if ((u32)tid < nbins) {
+#pragma unroll
+            for (int cp = 0; cp < FUSE_COPIES; cp++) {
+                u32 *g = fc.ghist + ((size_t)(rel * FUSE_COPIES + cp) * FUSE_MAX_BINS + tid) * FUSE_STRIDE32;
+                c += __hip_atomic_load(g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(g, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);       // left clean for the next call
+            }
+        }
+        u32 tot;
+        const u32 ex = block_excl_scan<PART_THREADS>(c, wsum, tot);
+        if ((u32)tid < nbins) {
+            st[rel][tid] = ex;
+            y.part_start[tid] = ex;
+            fc.cursor[((size_t)rel * FUSE_MAX_BINS + tid) * FUSE_STRIDE64] = ex;
+        }
+        if (tid == 0) { st[rel][nbins] = y.n; y.part_start[nbins] = y.n; }
+    }
+    if (tid == 0) __hip_atomic_store(fc.ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (tid < 8) __hip_atomic_store(&ft.counters[tid], (u64)0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // the join counters
+    __syncthreads();
+    // ---- the join task list (k_make_tasks's rules; one workgroup sees every partition: nbins <= PART_THREADS) ----------
+    const u32 k = tid;
+    u64 nr = 0, ns = 0, r0 = 0, s0 = 0;
+    if (k < nbins) { r0 = st[0][k]; nr = st[0][k + 1] - r0; s0 = st[1][k]; ns = st[1][k + 1] - s0; }
+    u64 mr = nr, ms = ns;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        const u64 p = __shfl_down(mr, off, 64), q = __shfl_down(ms, off, 64);
+        mr = p > mr ? p : mr;
+        ms = q > ms ? q : ms;
+    }
+    if ((tid & 63) == 0) { wmax[0][tid >> 6] = mr; wmax[1][tid >> 6] = ms; }
+    __syncthreads();
+    u64 maxR = 0, maxS = 0;
+    for (int i = 0; i < PART_THREADS / 64; i++) { maxR = wmax[0][i] > maxR ? wmax[0][i] : maxR; maxS = wmax[1][i] > maxS ? wmax[1][i] : maxS; }
+    u32 nt = 0, bis = 0;
+    u64 pbeg = 0, plen = 0, bbeg = 0, blen = 0;
+    if (k < nbins && nr != 0 && ns != 0) {
+        const u64 meanR = a.r[0].n / nbins + 1, meanS = a.r[1].n / nbins + 1;
+        const bool skewR = maxR > 16 * meanR, skewS = maxS > 16 * meanS;
+        bool build_S = nr >= ns;                                    // JobScheduler.cpp:187 (+ the skew exception of k_make_tasks)
+        if (skewS && !skewR && nr <= 2 * (u64)ft.table_tuples) build_S = false;
+        if (skewR && !skewS && ns <= 2 * (u64)ft.table_tuples) build_S = true;
+        if (build_S) { pbeg = r0; plen = nr; bbeg = s0; blen = ns; bis = 1; }
+        else         { pbeg = s0; plen = ns; bbeg = r0; blen = nr; bis = 0; }
+        nt = (u32)((plen + ft.probe_split - 1) / ft.probe_split);
+    }
+    u32 tot;
+    const u32 ex = block_excl_scan<PART_THREADS>(nt, wsum, tot);
+    u32 slot = ex;
+    for (u32 j = 0; j < nt; j++, slot++) {
+        if (slot >= ft.max_tasks) break;
+        JoinTask t;
+        t.pbeg = pbeg + (u64)j * ft.probe_split;
+        const u64 rem = plen - (u64)j * ft.probe_split;
+        t.plen = (u32)(rem < ft.probe_split ? rem : ft.probe_split);
+        t.part = k;
+        t.bbeg = bbeg;
+        t.blen = (u32)blen;
+        t.build_is_S = bis;
+        ft.tasks[slot] = t;
+    }
+    if (tid == 0) {
+        __hip_atomic_store(&ft.counters[1], (u64)(tot < ft.max_tasks ? tot : ft.max_tasks), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ntasks
+        __hip_atomic_store(&ft.counters[2], maxR, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(&ft.counters[3], maxS, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
+
+template <int THREADS>
+__global__ void __launch_bounds__(THREADS) k_scatter_fused2(PassPair a, int shift, int bits, FuseCtl fc)
+{
+    const PassRel &x = a.r[blockIdx.y];
+    dev_scatter_wc<THREADS>(x.in, x.out, nullptr, nullptr, 1u, x.L, shift, bits, nullptr, (const u64 *)nullptr, 0u, blockIdx.x,
+                            nullptr, nullptr, 0, a.mix, x.unit_hist, fc.cursor + (size_t)blockIdx.y * FUSE_MAX_BINS * FUSE_STRIDE64, x.n);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1360,6 +1531,24 @@ __device__ __forceinline__ u32 bj_bucket(u64 v, int radix_bits)
 // result that outgrows the landing zone needs no second run: the rest is fetched from `out`.
 struct DirectJoin { u32 nb, np, build_is_S, split; u64 *host_count; u32 *done; Pair *host_out; u64 host_cap; };
 
+// Task-list launches (not DIRECT) with dj.host_count set: the LAST workgroup of the launch copies the seven join counters
+// (count, ntasks, largest partitions, error words) to pinned host memory, so that the host learns the result count from its
+// stream synchronisation alone, without a device-to-host copy behind the kernel (one-pass joins: ~10 us of a ~90 us join).
+__device__ __forceinline__ void bj_publish(const DirectJoin &dj, const u64 *__restrict__ counters)
+{
+    // No fences: every atomicAdd of this workgroup on the result counter has RETURNED (its value placed the pairs) before
+    // the ticket is taken, the last workgroup reads the counters with device-scope atomic loads, and the host reads the pinned
+    // block only after the stream has synchronised (the end of a kernel releases at system scope).  (A fence per workgroup is
+    // an L2 write-back of the pairs it has just stored: [measured] 35 -> 52 us for the 10^6 x 10^6 join.)
+    if (dj.host_count == nullptr || threadIdx.x != 0) return;
+    if (__hip_atomic_fetch_add(dj.done, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1) {
+        for (int i = 0; i < 7; i++)
+            __hip_atomic_store(&dj.host_count[i], __hip_atomic_load(&counters[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), __ATOMIC_RELAXED,
+                               __HIP_MEMORY_SCOPE_SYSTEM);
+        __hip_atomic_store(dj.done, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
+
 // A partitioned relation as the join kernels read it: 16-byte tuples, or the narrow {payload 8 B, rowID 4 B} arrays that
 // k_scatter_wcn writes (NARROW: the build phase then reads 8 B per tuple and the rowID re-fetch 4 B instead of 16 + 16)
 // Buffer descriptors over a partition slice (k_join_ct): a load is then `descriptor + lane offset (one VGPR for all slot rows)
@@ -1453,7 +1642,7 @@ k_join_bkt(const RelView<NARROW> R, const RelView<NARROW> S, const JoinTask *__r
         task.build_is_S = dj.build_is_S;
     } else {
         const u32 nt = *ntasks;
-        if (blockIdx.x >= nt) return;
+        if (blockIdx.x >= nt) { bj_publish(dj, out_count); return; }
         task = tasks[blockIdx.x];
     }
     const bool build_is_S = task.build_is_S != 0;
@@ -1630,6 +1819,10 @@ k_join_bkt(const RelView<NARROW> R, const RelView<NARROW> S, const JoinTask *__r
             // wtot / gres are rewritten only after the next tile's first barrier: safe without another one
         }
         __syncthreads();         // the table is rebuilt by the next chunk
+    }
+    if (!DIRECT && dj.host_count != nullptr) {
+        __syncthreads();
+        bj_publish(dj, out_count);
     }
     if (DIRECT && dj.host_count != nullptr) {
         __syncthreads();                                                     // every store / atomic of this workgroup has been issued
@@ -2281,6 +2474,8 @@ static void allow_big_lds()
     SET_LDS(k_scatter_wc<WC_THREADS_SMALL>, wc_lds_bytes(WC_MAX_BITS, WC_THREADS_SMALL));
     SET_LDS(k_scatter_wc2<WC_THREADS>, wc_lds_bytes(WC_MAX_BITS, WC_THREADS));
     SET_LDS(k_scatter_wc2<WC_THREADS_SMALL>, wc_lds_bytes(WC_MAX_BITS, WC_THREADS_SMALL));
+    SET_LDS(k_scatter_fused2<WC_THREADS>, wc_lds_bytes(WC_MAX_BITS, WC_THREADS));
+    SET_LDS(k_scatter_fused2<WC_THREADS_SMALL>, wc_lds_bytes(WC_MAX_BITS, WC_THREADS_SMALL));
     SET_LDS((k_join_bkt<BJ_THREADS, BJ_CHUNK, BJ_BUCKET_BITS, BJ_EPT, false>), bj_lds_bytes(BJ_THREADS, BJ_CHUNK, BJ_BUCKET_BITS));
     SET_LDS((k_join_bkt<BJ_THREADS, BJ_CHUNK, BJ_BUCKET_BITS, BJ_EPT, true>), bj_lds_bytes(BJ_THREADS, BJ_CHUNK, BJ_BUCKET_BITS));
     SET_LDS((k_join_bkt<BJ_THREADS, BJ_CHUNK, BJ_BUCKET_BITS, BJ_EPT, false, true>), bj_lds_bytes(BJ_THREADS, BJ_CHUNK, BJ_BUCKET_BITS));
@@ -2411,6 +2606,51 @@ void launch_pass_pair(hipStream_t st, const PassPairHost &h, int shift, int bits
                            st, a, shift, bits);
     } else {
         hipLaunchKernelGGL(k_scatter_wc2<WC_THREADS>, dim3(mu, 2), dim3(WC_THREADS), wc_lds_bytes(bits, WC_THREADS), st, a, shift, bits);
+    }
+}
+
+// One-pass join, partition phase in two launches (k_hist_fused2, k_scatter_fused2).  d_ctl: FUSE_CTL_BYTES of HBM, zero
+// between calls (see FuseCtl).  phase 0: histogram + boundaries + task list; phase 1: scatter.
+constexpr size_t FUSE_CURSOR_BYTES = (size_t)2 * FUSE_MAX_BINS * FUSE_STRIDE64 * 8;
+constexpr size_t FUSE_GHIST_BYTES = (size_t)2 * FUSE_COPIES * FUSE_MAX_BINS * FUSE_STRIDE32 * 4;
+size_t fuse_ctl_bytes() { return FUSE_CURSOR_BYTES + FUSE_GHIST_BYTES + 256; }
+u32 *fuse_join_ticket(void *d_ctl) { return (u32 *)((unsigned char *)d_ctl + FUSE_CURSOR_BYTES + FUSE_GHIST_BYTES + 128); }
+void launch_fused_pass(hipStream_t st, const PassPairHost &h, int bits, int phase, void *d_ctl, u32 probe_split, u32 max_tasks,
+                       u32 table_tuples, JoinTask *d_tasks, u64 *d_counters)
+{
+    allow_big_lds();
+    PassPair a;
+    a.mix = h.mix;
+    u32 mu = 0;
+    for (int i = 0; i < 2; i++) {
+        const PassSide &x = h.side[i];
+        a.r[i] = PassRel{(const Tup *)x.in, (Tup *)x.out, x.seg_start, x.unit_start, x.unit_hist, x.unit_base, x.part_start,
+                         x.scan_tmp, x.g.n, x.g.L, x.g.max_units};
+        const u32 units = (u32)((x.g.n + x.g.L - 1) / x.g.L);
+        mu = units > mu ? units : mu;
+    }
+    if (mu == 0) mu = 1;                                                     // (both relations empty: the ticket logic still runs)
+    FuseCtl fc;
+    fc.cursor = (u64 *)d_ctl;
+    fc.ghist = (u32 *)((unsigned char *)d_ctl + FUSE_CURSOR_BYTES);
+    fc.ticket = (u32 *)((unsigned char *)d_ctl + FUSE_CURSOR_BYTES + FUSE_GHIST_BYTES);
+    if (phase == 0) {
+        // units per workgroup: as few global-histogram atomics as a full chip allows (>= ~2 workgroups per CU stay)
+        static const u32 forced_k = getenv("RHJ_FUSE_K") ? (u32)atoi(getenv("RHJ_FUSE_K")) : 0u;      // tuning aid
+        // ([measured] 10^6 x 10^6, 8 bits: k = 1 / 2 / 4 -> 27 / 24 / 24 us; 4 * 10^6, 9 bits: k = 1 / 2 / 4 / 8 -> 81 / 61 / 55 / 53 us):
+        // at most ~32 K atomics per launch while at least 64 workgroups per relation remain, at most 8 units each
+        u32 k = (u32)(((u64)mu * ((u64)2 << bits) + 32767) / 32768);
+        if (k > mu / 64) k = mu / 64;
+        if (k > 8) k = 8;
+        if (forced_k) k = forced_k;
+        if (k < 1) k = 1;
+        const FuseTasks ft{probe_split, max_tasks, table_tuples, k, d_tasks, d_counters};
+        hipLaunchKernelGGL(k_hist_fused2, dim3((mu + k - 1) / k, 2), dim3(PART_THREADS), ((size_t)8 << bits), st, a, 0, bits, fc, ft);
+    } else if (wc_threads_for(bits) == WC_THREADS_SMALL) {
+        hipLaunchKernelGGL(k_scatter_fused2<WC_THREADS_SMALL>, dim3(mu, 2), dim3(WC_THREADS_SMALL), wc_lds_bytes(bits, WC_THREADS_SMALL),
+                           st, a, 0, bits, fc);
+    } else {
+        hipLaunchKernelGGL(k_scatter_fused2<WC_THREADS>, dim3(mu, 2), dim3(WC_THREADS), wc_lds_bytes(bits, WC_THREADS), st, a, 0, bits, fc);
     }
 }
 
@@ -2588,10 +2828,13 @@ void launch_make_tasks(hipStream_t st, const u64 *d_startR, const u64 *d_startS,
 void launch_join(hipStream_t st, const void *d_R, const u64 *d_startR, const void *d_S, const u64 *d_startS,
                  const JoinTask *d_tasks, const u32 *d_ntasks, u32 grid, int radix_bits,
                  void *d_out, u64 out_capacity, u64 *d_out_count, int kind, const u32 *d_RK, const u32 *d_SK,
-                 const u64 *d_tag_base, const u32 *d_skip)
+                 const u64 *d_tag_base, const u32 *d_skip, u64 *host_pub, u32 *d_done)
 {
     if (grid == 0) return;
     allow_big_lds();
+    DirectJoin pub{};                                                        // (JK_BKT / JK_BKT_BIG over 16-byte tuples only)
+    pub.host_count = host_pub;
+    pub.done = d_done;
     const RelView<false> vR{(const Tup *)d_R}, vS{(const Tup *)d_S};
     if (d_RK != nullptr) {                                                   // narrow partitions (k_scatter_wcn): d_R, d_S are payload arrays
         const RelView<true> nR{(const u64 *)d_R, d_RK}, nS{(const u64 *)d_S, d_SK};
@@ -2621,13 +2864,13 @@ void launch_join(hipStream_t st, const void *d_R, const u64 *d_startR, const voi
     if (kind == JK_BKT) {
         hipLaunchKernelGGL((k_join_bkt<BJ_THREADS, BJ_CHUNK, BJ_BUCKET_BITS, BJ_EPT, false>), dim3(grid), dim3(BJ_THREADS),
                            bj_lds_bytes(BJ_THREADS, BJ_CHUNK, BJ_BUCKET_BITS), st, vR, vS,
-                           d_tasks, d_ntasks, radix_bits, (Pair *)d_out, out_capacity, d_out_count, DirectJoin{});
+                           d_tasks, d_ntasks, radix_bits, (Pair *)d_out, out_capacity, d_out_count, pub);
         return;
     }
     if (kind == JK_BKT_BIG) {
         hipLaunchKernelGGL((k_join_bkt<BJ2_THREADS, BJ2_CHUNK, BJ2_BUCKET_BITS, BJ2_EPT, false>), dim3(grid), dim3(BJ2_THREADS),
                            bj_lds_bytes(BJ2_THREADS, BJ2_CHUNK, BJ2_BUCKET_BITS), st, vR, vS,
-                           d_tasks, d_ntasks, radix_bits, (Pair *)d_out, out_capacity, d_out_count, DirectJoin{});
+                           d_tasks, d_ntasks, radix_bits, (Pair *)d_out, out_capacity, d_out_count, pub);
         return;
     }
     if (kind == JK_CT_HALF_MID) {

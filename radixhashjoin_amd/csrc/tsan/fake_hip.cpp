@@ -182,9 +182,19 @@ static void fake_join(void *d_out, u64 cap, u64 *d_out_count, u64 *host_count, v
     else *d_out_count = at + FAKE_PAIRS;
 }
 void launch_join(hipStream_t st, const void *, const u64 *, const void *, const u64 *, const JoinTask *, const u32 *, u32, int,
-                 void *d_out, u64 out_capacity, u64 *d_out_count, int, const u32 *, const u32 *, const u64 *, const u32 *)
+                 void *d_out, u64 out_capacity, u64 *d_out_count, int, const u32 *, const u32 *, const u64 *, const u32 *, u64 *host_pub,
+                 u32 *)
 {
-    fake_enqueue(st, [=] { fake_join(d_out, out_capacity, d_out_count, nullptr, nullptr, 0); });
+    fake_enqueue(st, [=] {
+        fake_join(d_out, out_capacity, d_out_count, nullptr, nullptr, 0);
+        if (host_pub) for (int i = 0; i < 7; i++) host_pub[i] = d_out_count[i];      // (the last workgroup publishes the counters)
+    });
+}
+size_t fuse_ctl_bytes() { return 12352; }
+u32 *fuse_join_ticket(void *d_ctl) { return (u32 *)((unsigned char *)d_ctl + 12288) + 1; }
+void launch_fused_pass(hipStream_t st, const PassPairHost &, int, int phase, void *, u32, u32, u32, JoinTask *, u64 *d_counters)
+{
+    if (phase == 0) fake_enqueue(st, [=] { memset(d_counters, 0, 64); });           // (its last workgroup clears the join counters)
 }
 void launch_join_direct(hipStream_t st, const void *, u64, const void *, u64, void *d_out, u64 out_capacity, u64 *d_out_count,
                         u64 *host_count, u32 *, void *host_out, u64 host_cap)

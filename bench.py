@@ -384,6 +384,19 @@ def extras(eng, torch, dev, steps, which="all"):
     sec = (time.perf_counter() - t0) / reps
     res["small_work_94_joins_rhj_join"] = {"total_ms": sec * 1e3, "mean_us_per_join": sec / len(cases) * 1e6,
                                            "tuples_per_s": sum(len(a) + len(b) for a, b in cases) / sec}
+    # ... and through rhj_join_batch from the same ONE thread: sixteen joins per launch, one staged upload and one
+    # synchronisation per sixteen (the kernel writes the pairs into pinned host memory itself)
+    eng.join_batch(cases, keep_pairs=False)
+    secs_b = []
+    for _ in range(reps):
+        cnts, dt_b = eng.join_batch(cases, keep_pairs=False, timed=True)
+        secs_b.append(dt_b)
+    sec_b = sorted(secs_b)[len(secs_b) // 2]
+    single_counts = [eng.join_count_only_page(Rt, St) for Rt, St in cases]
+    res["small_work_94_joins_rhj_join_batch"] = {"total_ms": sec_b * 1e3, "mean_us_per_join": sec_b / len(cases) * 1e6,
+                                                 "tuples_per_s": sum(len(a) + len(b) for a, b in cases) / sec_b,
+                                                 "same_counts_as_rhj_join": [int(c) for c in cnts] == [int(c) for c in single_counts],
+                                                 "note": "ONE caller thread, the C call alone (pages freed outside), median of %d" % reps}
     # the same 94 joins the way the reference issues them: 8 query threads (join.cpp:42-43, MainScheduler.cpp:6-14), each
     # with its own scheduler = its own rhj_ctx and HIP stream; ctypes releases the GIL inside the C call
     import threading

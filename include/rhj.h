@@ -143,6 +143,16 @@ int  rhj_plan(uint64_t nR, uint64_t nS, const rhj_opts *in, rhj_opts *resolved);
 int rhj_join(rhj_ctx *ctx, const rhj_tuple *R, uint64_t nR, const rhj_tuple *S, uint64_t nS,
              const rhj_opts *opts, void **out_page, uint64_t *out_count);
 
+/* ---- several joins in one call (MainScheduler.cpp:6-30 / join.cpp:42-50 keep 8 queries in flight) -------------
+ * out_pages[i] / out_counts[i] are what rhj_join(ctx, joins[i].R, .., NULL, &page, &count) would return, for every i.  Joins small
+ * enough for the one-launch path (every join of small.work: <= 43 K tuples) run SIXTEEN PER LAUNCH: their inputs are staged
+ * into one pinned buffer by a few helper threads and cross PCIe in one copy, one kernel launch joins them (grid.y = join), the
+ * pairs land in pinned host memory written by the kernel itself, one synchronisation -- instead of two copies, a launch and a
+ * synchronisation per join.  Larger joins of the list take the rhj_join path one by one.  On an error every page already
+ * produced is freed and all counts are zero. */
+typedef struct { const rhj_tuple *R; uint64_t nR; const rhj_tuple *S; uint64_t nS; } rhj_join_desc;
+int rhj_join_batch(rhj_ctx *ctx, uint32_t n, const rhj_join_desc *joins, void **out_pages, uint64_t *out_counts);
+
 /* ---- device-resident variant (inputs/outputs already in HBM).  d_out may be NULL with
  * out_capacity 0 to count only.  Returns RHJ_E_OVERFLOW (and the exact *out_count) when
  * out_capacity is too small; call again with a larger buffer. */

@@ -24,6 +24,11 @@ class Opts(C.Structure):
         return f"Opts(passes={self.passes}, bits1={self.bits1}, bits2={self.bits2}, probe_split={self.probe_split})"
 
 
+class JoinDesc(C.Structure):
+    """rhj_join_desc (include/rhj.h): one join of an rhj_join_batch call"""
+    _fields_ = [("R", C.c_void_p), ("nR", C.c_uint64), ("S", C.c_void_p), ("nS", C.c_uint64)]
+
+
 class Timings(C.Structure):
     _fields_ = [("ms", C.c_double * 6), ("launches", C.c_uint32 * 6), ("total_ms", C.c_double),
                 ("passes", _i32), ("bits1", _i32), ("bits2", _i32), ("ntasks", _u64)]
@@ -66,6 +71,7 @@ SYMBOLS = {
     "rhj_default_opts": (None, [_P(Opts)]),
     "rhj_plan": (C.c_int, [_u64, _u64, _P(Opts), _P(Opts)]),
     "rhj_join": (C.c_int, [_vp, _vp, _u64, _vp, _u64, _P(Opts), _P(_vp), _P(_u64)]),
+    "rhj_join_batch": (C.c_int, [_vp, C.c_uint32, _P(JoinDesc), _P(_vp), _P(_u64)]),
     "rhj_join_dev": (C.c_int, [_vp, _vp, _u64, _vp, _u64, _P(Opts), _vp, _u64, _P(_u64)]),
     "rhj_histogram": (C.c_int, [_vp, _vp, _u64, C.c_int, C.c_int, _vp]),
     "rhj_prefix": (C.c_int, [_vp, _vp, _u64, _vp]),
@@ -322,6 +328,36 @@ class Engine:
         else:
             assert n.value == 0
         return out
+
+    def join_batch(self, joins, keep_pairs=True, timed=False):
+        """rhj_join_batch over a list of (R, S) host relations: list of pair arrays (or of counts with keep_pairs=False: the pages
+        are then freed right away, as ~Result does); timed: also the seconds spent inside the C call"""
+        import time
+        rel = [(np.ascontiguousarray(R, dtype=TUPLE), np.ascontiguousarray(S, dtype=TUPLE)) for R, S in joins]
+        n = len(rel)
+        desc = (JoinDesc * max(n, 1))()
+        for i, (R, S) in enumerate(rel):
+            desc[i] = JoinDesc(R.ctypes.data, len(R), S.ctypes.data, len(S))
+        pages, counts = (_vp * max(n, 1))(), (_u64 * max(n, 1))()
+        t0 = time.perf_counter()
+        rc = self.lib.rhj_join_batch(self.ctx, n, desc, pages, counts)
+        dt = time.perf_counter() - t0
+        self._chk(rc)
+        out = []
+        for i in range(n):
+            if keep_pairs:
+                a = np.empty(counts[i], dtype=PAIR)
+                if pages[i]:
+                    assert C.c_uint64.from_address(pages[i]).value == 0          # bucket_info::next
+                    C.memmove(a.ctypes.data, pages[i] + 8, a.nbytes)
+                else:
+                    assert counts[i] == 0
+                out.append(a)
+            else:
+                out.append(int(counts[i]))
+            if pages[i]:
+                _libc_free(_vp(pages[i]))
+        return (out, dt) if timed else out
 
     def join_count_only_page(self, R, S, opts=None, timed=False):
         """rhj_join exactly as the C++ mirror calls it, the result page freed right away (what ~Result does): for

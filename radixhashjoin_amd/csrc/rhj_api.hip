@@ -90,6 +90,76 @@ struct Stager {
     }
 };
 
+// A few helper threads that copy a list of memory segments side by side (rhj_join_batch: staging the inputs of sixteen small
+// joins into pinned memory, filling sixteen result pages).  One job at a time; the caller copies too.
+struct CopySeg { void *dst; const void *src; size_t bytes; };
+struct CopyPool {
+    std::vector<std::thread> th;
+    std::mutex mu;
+    std::condition_variable cv, idle;
+    const CopySeg *segs = nullptr;
+    size_t nseg = 0;
+    std::atomic<size_t> next{0};
+    u64 gen = 0;
+    int active = 0;
+    bool quit = false;
+    explicit CopyPool(int n)
+    {
+        try {
+            for (int i = 0; i < n; i++) th.emplace_back([this] { work(); });
+        } catch (...) {}                                   // fewer helpers (or none): the caller copies everything itself
+    }
+    ~CopyPool()
+    {
+        { std::lock_guard<std::mutex> lk(mu); quit = true; }
+        cv.notify_all();
+        for (std::thread &t : th) t.join();
+    }
+    void drain()
+    {
+        for (;;) {
+            const size_t i = next.fetch_add(1);
+            if (i >= nseg) return;
+            if (segs[i].src) memcpy(segs[i].dst, segs[i].src, segs[i].bytes);
+            else memset(segs[i].dst, 0, segs[i].bytes);              // (no source: first touch of fresh pages)
+        }
+    }
+    void work()
+    {
+        u64 seen = 0;
+        for (;;) {
+            {
+                std::unique_lock<std::mutex> lk(mu);
+                cv.wait(lk, [&] { return quit || gen != seen; });
+                if (quit) return;
+                seen = gen;
+            }
+            drain();
+            {
+                std::lock_guard<std::mutex> lk(mu);
+                active--;
+            }
+            idle.notify_all();
+        }
+    }
+    void run(const std::vector<CopySeg> &list)
+    {
+        if (list.empty()) return;
+        {
+            std::lock_guard<std::mutex> lk(mu);
+            segs = list.data();
+            nseg = list.size();
+            next.store(0);
+            active = (int)th.size();
+            gen++;
+        }
+        cv.notify_all();
+        drain();
+        std::unique_lock<std::mutex> lk(mu);
+        idle.wait(lk, [&] { return active == 0; });
+    }
+};
+
 struct rhj_ctx {
     int device = 0;
     hipStream_t own_stream = nullptr;
@@ -109,6 +179,15 @@ struct rhj_ctx {
     bool small_hdr_clean = false;      // the header has been zeroed behind the previous small join
     DevBuf hist_tmp, scan_tmp, hist2, grp_rng, unit_start2, seg_rng, tag_base;
     DevBuf shard_ps[2], shard_mm;      // multi-GPU sender: class boundaries per side, rowID {min, max} per side
+    // rhj_join_batch: several small joins per launch
+    struct CopyPool *pool = nullptr;   // helper threads for host memcpy (staging in, pages out)
+    // (two slots: the host work of one group of joins overlaps the GPU work of the next)
+    unsigned char *b_stage[2] = {nullptr, nullptr};  // pinned: descriptors + the inputs of one group of joins
+    size_t b_stage_cap[2] = {0, 0};
+    unsigned char *b_land[2] = {nullptr, nullptr}, *b_land_dev[2] = {nullptr, nullptr};   // pinned: 16 counts (128 B) + the group's first pairs, written by the kernel itself
+    size_t b_land_cap[2] = {0, 0};
+    DevBuf b_in[2], b_out[2], b_cnt[2];   // device: staged blob, pair buffers, per-join {count, ticket}
+    hipEvent_t b_ev[2] = {nullptr, nullptr};
     DevBuf fuse_ctl;                   // one-pass joins in three launches: global histograms, digit cursors, tickets (k_hist_fused2)
     bool fuse_clean = false;           // ... which the kernels leave zeroed (false: the next call clears them first)
     u64 *h_pub = nullptr, *h_pub_dev = nullptr;   // pinned: the join counters as the bucket join's last workgroup publishes them
@@ -1192,7 +1271,8 @@ int rhj_release_workspace(rhj_ctx *ctx)
                      &ctx->unit_start_b, &ctx->unit_hist_b, &ctx->unit_base_b, &ctx->scan_tmp_b, &ctx->tasks,
                      &ctx->counters, &ctx->out_pairs, &ctx->small_out, &ctx->hist_tmp, &ctx->scan_tmp, &ctx->hist2,
                      &ctx->grp_rng, &ctx->unit_start2, &ctx->narrow_flag, &ctx->seg_rng, &ctx->tag_base,
-                     &ctx->shard_ps[0], &ctx->shard_ps[1], &ctx->shard_mm, &ctx->shard_wide, &ctx->fuse_ctl};
+                     &ctx->shard_ps[0], &ctx->shard_ps[1], &ctx->shard_mm, &ctx->shard_wide, &ctx->fuse_ctl, &ctx->b_in[0], &ctx->b_out[0], &ctx->b_cnt[0],
+                     &ctx->b_in[1], &ctx->b_out[1], &ctx->b_cnt[1]};
     ctx->fuse_clean = false;
     for (DevBuf *b : all) release(*b);
     ctx->small_hdr_clean = false;
@@ -1221,6 +1301,12 @@ void rhj_destroy(rhj_ctx *ctx)
     if (ctx->copy_stream) (void)hipStreamDestroy(ctx->copy_stream);
     if (ctx->down_stream) (void)hipStreamDestroy(ctx->down_stream);
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
+    delete ctx->pool;
+    for (int i = 0; i < 2; i++) {
+        if (ctx->b_stage[i]) (void)hipHostFree(ctx->b_stage[i]);
+        if (ctx->b_land[i]) (void)hipHostFree(ctx->b_land[i]);
+        if (ctx->b_ev[i]) (void)hipEventDestroy(ctx->b_ev[i]);
+    }
     delete ctx;
 }
 
@@ -1760,6 +1846,220 @@ int rhj_join(rhj_ctx *ctx, const rhj_tuple *R, uint64_t nR, const rhj_tuple *S, 
                 ms(tK, now()), ms(t0, now()));
     *out_page = page;
     *out_count = count;
+    return RHJ_OK;
+}
+
+// ---- several small joins per launch (MainScheduler.cpp:6-30 / join.cpp:42-50: the reference keeps 8 queries in
+// flight; their joins are so small -- <= 43 K tuples on small.work -- that launch, copy and synchronisation latencies are
+// their whole cost) ------------------------------------------------------------------------------------------------------
+namespace {
+
+constexpr u32 BATCH_MAX = 16;                           // joins per launch (grid.y)
+constexpr size_t BATCH_PIECE = (size_t)256 << 10;       // host copies are cut into pieces of this size for the helper threads
+
+int ensure_pinned(rhj_ctx *ctx, unsigned char **p, size_t *cap, size_t bytes, unsigned char **dev = nullptr)
+{
+    if (*cap >= bytes) return RHJ_OK;
+    if (*p) { (void)hipHostFree(*p); *p = nullptr; *cap = 0; }
+    size_t want = (size_t)8 << 20;
+    while (want < bytes) want <<= 1;
+    HIPCHK(ctx, hipHostMalloc((void **)p, want, hipHostMallocDefault));
+    *cap = want;
+    if (dev) {
+        if (hipHostGetDevicePointer((void **)dev, *p, 0) != hipSuccess || !*dev) {
+            (void)hipGetLastError();
+            (void)hipHostFree(*p);
+            *p = nullptr; *cap = 0;
+            return fail(ctx, RHJ_E_HIP, "no device address for pinned host memory");
+        }
+    }
+    return RHJ_OK;
+}
+
+void add_pieces(std::vector<CopySeg> &v, void *dst, const void *src, size_t bytes)
+{
+    for (size_t o = 0; o < bytes; o += BATCH_PIECE)
+        v.push_back(CopySeg{(char *)dst + o, (const char *)src + o, bytes - o < BATCH_PIECE ? bytes - o : BATCH_PIECE});
+}
+
+// One group of <= BATCH_MAX direct joins = ONE staged upload, ONE launch, ONE wait.  A context has two slots (staging buffer,
+// device buffers, landing zone, counters, event), so that the host work of a group -- staging its inputs, filling its
+// result pages -- overlaps the GPU work of its neighbour:   stage(g+1) | GPU(g)   and   pages(g) | GPU(g+1).
+struct BatchSlot {
+    u32 k = 0;
+    const u32 *idx = nullptr;
+    size_t in_bytes = 0, out_off[BATCH_MAX] = {0}, land_off[BATCH_MAX] = {0};
+    u64 dcap[BATCH_MAX] = {0}, lcap[BATCH_MAX] = {0};
+    u32 max_blocks = 0;
+};
+
+int batch_stage(rhj_ctx *ctx, int sl, BatchSlot &b, const rhj_join_desc *J, const u32 *idx, u32 k)
+{
+    const size_t A = 256;
+    auto up = [&](size_t x) { return (x + A - 1) & ~(A - 1); };
+    size_t in_off[BATCH_MAX][2];
+    size_t in_bytes = up(BATCH_MAX * sizeof(BatchJoinDesc)), out_bytes = 0, land_bytes = 128;
+    b.k = k;
+    b.idx = idx;
+    for (u32 i = 0; i < k; i++) {
+        const rhj_join_desc &j = J[idx[i]];
+        in_off[i][0] = in_bytes; in_bytes += up((size_t)j.nR * 16);
+        in_off[i][1] = in_bytes; in_bytes += up((size_t)j.nS * 16);
+        const u64 guess = (j.nR > j.nS ? j.nR : j.nS) + 1024;
+        b.lcap[i] = guess;                                  // what a foreign-key join yields lands in pinned memory ...
+        b.dcap[i] = guess * 32;                             // ... a many-to-many result still fits the device buffer
+        b.out_off[i] = out_bytes; out_bytes += up((size_t)b.dcap[i] * 16);
+        b.land_off[i] = land_bytes; land_bytes += up((size_t)b.lcap[i] * 16);
+    }
+    b.in_bytes = in_bytes;
+    RHJCHK(ensure_pinned(ctx, &ctx->b_stage[sl], &ctx->b_stage_cap[sl], in_bytes));
+    RHJCHK(ensure_pinned(ctx, &ctx->b_land[sl], &ctx->b_land_cap[sl], land_bytes, &ctx->b_land_dev[sl]));
+    RHJCHK(ensure(ctx, ctx->b_in[sl], in_bytes));
+    RHJCHK(ensure(ctx, ctx->b_out[sl], out_bytes));
+    if (!ctx->b_cnt[sl].p) {
+        RHJCHK(ensure(ctx, ctx->b_cnt[sl], BATCH_MAX * 16));
+        HIPCHK(ctx, hipMemsetAsync(ctx->b_cnt[sl].p, 0, BATCH_MAX * 16, ctx->stream));  // the kernels leave it zeroed from here on
+    }
+    if (!ctx->b_ev[sl]) HIPCHK(ctx, hipEventCreateWithFlags(&ctx->b_ev[sl], hipEventDisableTiming));
+    BatchJoinDesc *desc = (BatchJoinDesc *)ctx->b_stage[sl];
+    volatile u64 *hcount = (volatile u64 *)ctx->b_land[sl];
+    std::vector<CopySeg> segs;
+    const u32 tile = join_direct_tile();
+    b.max_blocks = 0;
+    for (u32 i = 0; i < k; i++) {
+        const rhj_join_desc &j = J[idx[i]];
+        BatchJoinDesc &d = desc[i];
+        d.R = (const unsigned char *)ctx->b_in[sl].p + in_off[i][0];
+        d.S = (const unsigned char *)ctx->b_in[sl].p + in_off[i][1];
+        d.out = (unsigned char *)ctx->b_out[sl].p + b.out_off[i];
+        d.cap = b.dcap[i];
+        d.count = (u64 *)((unsigned char *)ctx->b_cnt[sl].p + (size_t)i * 16);
+        d.done = (u32 *)((unsigned char *)ctx->b_cnt[sl].p + (size_t)i * 16 + 8);
+        d.build_is_S = j.nR >= j.nS ? 1u : 0u;              // JobScheduler.cpp:187
+        d.nb = (u32)(d.build_is_S ? j.nS : j.nR);
+        d.np = (u32)(d.build_is_S ? j.nR : j.nS);
+        d.split = tile;
+        d.nblocks = (d.np + tile - 1) / tile;
+        d.pad = 0;
+        d.host_count = (u64 *)ctx->b_land_dev[sl] + i;
+        d.host_out = ctx->b_land_dev[sl] + b.land_off[i];
+        d.host_cap = b.lcap[i];
+        b.max_blocks = d.nblocks > b.max_blocks ? d.nblocks : b.max_blocks;
+        hcount[i] = ~0ull;
+        add_pieces(segs, ctx->b_stage[sl] + in_off[i][0], j.R, (size_t)j.nR * 16);
+        add_pieces(segs, ctx->b_stage[sl] + in_off[i][1], j.S, (size_t)j.nS * 16);
+    }
+    ctx->pool->run(segs);
+    return RHJ_OK;
+}
+
+int batch_launch(rhj_ctx *ctx, int sl, const BatchSlot &b)
+{
+    HIPCHK(ctx, hipMemcpyAsync(ctx->b_in[sl].p, ctx->b_stage[sl], b.in_bytes, hipMemcpyHostToDevice, ctx->stream));
+    {
+        Span s(ctx, RHJ_K_JOIN);
+        launch_join_batch(ctx->stream, (const BatchJoinDesc *)ctx->b_in[sl].p, b.k, b.max_blocks);
+    }
+    RHJCHK(check_launch(ctx, "batched direct join"));
+    HIPCHK(ctx, hipEventRecord(ctx->b_ev[sl], ctx->stream));
+    return RHJ_OK;
+}
+
+// the group's launch has finished (the caller waited for its event): counts, pages.  retry: joins whose result outgrew the
+// device buffer (they take the single-join path afterwards)
+int batch_finish(rhj_ctx *ctx, int sl, const BatchSlot &b, void **pages, uint64_t *counts, std::vector<u32> &retry)
+{
+    volatile u64 *hcount = (volatile u64 *)ctx->b_land[sl];
+    std::vector<CopySeg> segs, touch;
+    struct Tail { void *dst; const void *src; size_t bytes; };
+    std::vector<Tail> tails;                                   // what lies beyond a join's landing zone: fetched from HBM
+    for (u32 i = 0; i < b.k; i++) {
+        const u64 count = hcount[i];
+        if (count == ~0ull) {
+            (void)hipMemsetAsync(ctx->b_cnt[sl].p, 0, BATCH_MAX * 16, ctx->stream);
+            return fail(ctx, RHJ_E_HIP, "a batched join did not publish its result count");
+        }
+        pages[b.idx[i]] = nullptr;
+        counts[b.idx[i]] = count;
+        if (count == 0) continue;                            // head stays nullptr (Result::isEmpty)
+        if (count > b.dcap[i]) { retry.push_back(b.idx[i]); continue; }
+        unsigned char *page = (unsigned char *)malloc(8 + (size_t)count * 16);
+        if (!page) return fail(ctx, RHJ_E_NOMEM, "malloc of a result page failed");
+        memset(page, 0, 8);                                  // bucket_info::next = nullptr (Result.h:14-17)
+        pages[b.idx[i]] = page;
+        const u64 got = count < b.lcap[i] ? count : b.lcap[i];
+        add_pieces(segs, page + 8, ctx->b_land[sl] + b.land_off[i], (size_t)got * 16);
+        if (count > got) {                                   // beyond the landing zone: straight from HBM into the page
+            unsigned char *dst = page + 8 + got * 16;
+            const size_t bytes = (size_t)(count - got) * 16;
+            tails.push_back(Tail{dst, (const unsigned char *)ctx->b_out[sl].p + b.out_off[i] + got * 16, bytes});
+            if (bytes >= ((size_t)1 << 20)) {
+                // a DMA into fresh pages takes the page faults itself and runs at a third of the wire rate: fault the range in
+                // first, from the helper threads, in huge pages where the kernel grants them
+                const uintptr_t lo = ((uintptr_t)dst + ((uintptr_t)2 << 20) - 1) & ~(((uintptr_t)2 << 20) - 1);
+                const uintptr_t hi = ((uintptr_t)dst + bytes) & ~(((uintptr_t)2 << 20) - 1);
+                if (hi > lo) (void)madvise((void *)lo, hi - lo, MADV_HUGEPAGE);
+                for (size_t o = 0; o < bytes; o += BATCH_PIECE)
+                    touch.push_back(CopySeg{dst + o, nullptr, bytes - o < BATCH_PIECE ? bytes - o : BATCH_PIECE});
+            }
+        }
+    }
+    ctx->pool->run(touch);
+    if (!tails.empty()) {
+        // on its own stream: the next group's kernel is already running on ctx->stream (this group's has finished: its event)
+        if (!ctx->down_stream) HIPCHK(ctx, hipStreamCreateWithFlags(&ctx->down_stream, hipStreamNonBlocking));
+        for (const Tail &t : tails) HIPCHK(ctx, hipMemcpyAsync(t.dst, t.src, t.bytes, hipMemcpyDeviceToHost, ctx->down_stream));
+    }
+    ctx->pool->run(segs);                                    // the landing zones -> pages, while the tails travel
+    if (!tails.empty()) HIPCHK(ctx, hipStreamSynchronize(ctx->down_stream));
+    return RHJ_OK;
+}
+
+}  // namespace
+
+int rhj_join_batch(rhj_ctx *ctx, uint32_t n, const rhj_join_desc *joins, void **out_pages, uint64_t *out_counts)
+{
+    RHJCHK(use_device(ctx));
+    if (n && (!joins || !out_pages || !out_counts)) return fail(ctx, RHJ_E_INVALID, "rhj_join_batch: null argument");
+    prof_reset(ctx);
+    ctx->last_pipelined = 0;
+    for (u32 i = 0; i < n; i++) { out_pages[i] = nullptr; out_counts[i] = 0; }
+    auto free_all = [&]() { for (u32 i = 0; i < n; i++) { free(out_pages[i]); out_pages[i] = nullptr; out_counts[i] = 0; } };
+    std::vector<u32> small, single, retry;
+    for (u32 i = 0; i < n; i++) {
+        const rhj_join_desc &j = joins[i];
+        if (j.nR == 0 || j.nS == 0) continue;
+        if (!j.R || !j.S) return fail(ctx, RHJ_E_INVALID, "rhj_join_batch: null input relation");
+        rhj_opts plan;
+        if (resolve_plan(j.nR, j.nS, nullptr, &plan) != RHJ_OK) return fail(ctx, RHJ_E_INVALID, "bad rhj_opts");
+        (plan.passes == 0 && is_direct(ctx, 1, j.nR, j.nS) ? small : single).push_back(i);
+    }
+    if (!small.empty()) {
+        if (!ctx->pool) ctx->pool = new CopyPool((int)env_u64("RHJ_BATCH_THREADS", 3, 0, 15));
+        const size_t G = (small.size() + BATCH_MAX - 1) / BATCH_MAX;
+        BatchSlot slot[2];
+        auto group_k = [&](size_t g) { return (u32)(small.size() - g * BATCH_MAX < BATCH_MAX ? small.size() - g * BATCH_MAX : BATCH_MAX); };
+        int rc = batch_stage(ctx, 0, slot[0], joins, &small[0], group_k(0));
+        if (rc == RHJ_OK) rc = batch_launch(ctx, 0, slot[0]);
+        for (size_t g = 0; g < G && rc == RHJ_OK; g++) {
+            const int cur = (int)(g & 1), nxt = cur ^ 1;
+            if (g + 1 < G) rc = batch_stage(ctx, nxt, slot[nxt], joins, &small[(g + 1) * BATCH_MAX], group_k(g + 1));   // | GPU(g)
+            if (rc == RHJ_OK && hipEventSynchronize(ctx->b_ev[cur]) != hipSuccess) rc = fail(ctx, RHJ_E_HIP, "batched join: event wait failed");
+            if (rc == RHJ_OK && g + 1 < G) rc = batch_launch(ctx, nxt, slot[nxt]);
+            if (rc == RHJ_OK) rc = batch_finish(ctx, cur, slot[cur], out_pages, out_counts, retry);                        // | GPU(g+1)
+        }
+        if (rc != RHJ_OK) { (void)hipStreamSynchronize(ctx->stream); free_all(); return rc; }
+    }
+    ctx->last.passes = 0;
+    ctx->last.bits1 = ctx->last.bits2 = 0;
+    ctx->last_join_kind = -1;
+    ctx->cur_narrow = 0;
+    single.insert(single.end(), retry.begin(), retry.end());
+    for (u32 i : single) {                                   // too large for the one-launch path (or a result beyond 32x the guess)
+        const rhj_join_desc &j = joins[i];
+        const int rc = rhj_join(ctx, j.R, j.nR, j.S, j.nS, nullptr, &out_pages[i], &out_counts[i]);
+        if (rc != RHJ_OK) { free_all(); return rc; }
+    }
     return RHJ_OK;
 }
 

@@ -87,6 +87,20 @@ void launch_join(hipStream_t st, const void *d_R, const u64 *d_startR, const voi
 void launch_join_direct(hipStream_t st, const void *d_R, u64 nR, const void *d_S, u64 nS, void *d_out, u64 out_capacity,
                         u64 *d_out_count, u64 *host_count = nullptr, u32 *d_done = nullptr, void *host_out = nullptr,
                         u64 host_cap = 0);
+// one join of a batched direct launch (k_join_bkt<.., BATCH>): what launch_join_direct passes as kernel arguments, per join
+struct BatchJoinDesc {
+    const void *R, *S;          // 16-byte tuples in HBM
+    void *out;                  // pairs in HBM
+    u64 cap;                    // ... capacity (pairs)
+    u64 *count;                 // device result counter of this join (zero before, zero after)
+    u32 nblocks, nb, np, build_is_S, split, pad;
+    u64 *host_count;            // pinned host: the count, published by the join's last workgroup
+    u32 *done;                  // device ticket of this join (zero before, zero after)
+    void *host_out;             // pinned host landing zone of this join's first host_cap pairs
+    u64 host_cap;
+};
+void launch_join_batch(hipStream_t st, const BatchJoinDesc *d_batch, u32 njoins, u32 max_blocks);
+u32 join_direct_tile();
 void launch_checksum(hipStream_t st, const void *d_pairs, u64 n, u64 *d_sum);
 void launch_generate(hipStream_t st, int kind, void *d_out, u64 n, u64 row0, u64 D, u64 seed, double theta);
 void launch_expected_pkfk(hipStream_t st, const void *d_S, u64 n, u64 *d_sum);

@@ -1609,15 +1609,33 @@ template <> struct RelView<true> {
 // them again costs a second pass over the build payloads: measured 20 against 10 ms at 10^9 tuples): partitions for that
 // kernel get their global rowIDs from the last partition pass instead (k_scatter_wc<.., IN_NARROW>, 16-byte tuples out).
 // skip (optional): a device word that is non-zero when this join is going to be repeated in another format.
-template <int THREADS, int CHUNK, int BBITS, int EPT, bool DIRECT, bool NARROW = false, bool TAGGED = false>
+// BATCH (DIRECT only): ONE launch runs up to 16 independent small joins, blockIdx.y = join.  Everything a DIRECT launch gets
+// as kernel arguments comes from batch[blockIdx.y] instead (BatchJoinDesc, rhj_internal.h); every join publishes its own
+// count and leaves its own counters zeroed, as a DIRECT launch does.  (rhj_join_batch: MainScheduler's "several queries at
+// once", MainScheduler.cpp:6-30, for joins so small that launch and copy latencies are their whole cost.)
+template <int THREADS, int CHUNK, int BBITS, int EPT, bool DIRECT, bool NARROW = false, bool TAGGED = false, bool BATCH = false>
 __global__ void __launch_bounds__(THREADS, 4)
-k_join_bkt(const RelView<NARROW> R, const RelView<NARROW> S, const JoinTask *__restrict__ tasks,
+k_join_bkt(RelView<NARROW> R, RelView<NARROW> S, const JoinTask *__restrict__ tasks,
            const u32 *__restrict__ ntasks, int radix_bits, Pair *__restrict__ out, u64 out_capacity,
            u64 *__restrict__ out_count, DirectJoin dj, const u64 *__restrict__ tag_base = nullptr,
-           const u32 *__restrict__ skip = nullptr)
+           const u32 *__restrict__ skip = nullptr, const BatchJoinDesc *__restrict__ batch = nullptr)
 {
     static_assert(!TAGGED || (NARROW && !DIRECT), "sender tags exist in the narrow format only");
+    static_assert(!BATCH || (DIRECT && !NARROW), "batched launches are direct joins of 16-byte tuples");
     if (skip != nullptr && *skip != 0) return;
+    u32 nblocks = gridDim.x;                                                 // workgroups of THIS join
+    if constexpr (BATCH) {
+        const BatchJoinDesc b = batch[blockIdx.y];
+        if (blockIdx.x >= b.nblocks) return;
+        nblocks = b.nblocks;
+        R = RelView<false>{(const Tup *)b.R};
+        S = RelView<false>{(const Tup *)b.S};
+        out = (Pair *)b.out;
+        out_capacity = b.cap;
+        out_count = b.count;
+        dj.nb = b.nb; dj.np = b.np; dj.build_is_S = b.build_is_S; dj.split = b.split;
+        dj.host_count = b.host_count; dj.done = b.done; dj.host_out = (Pair *)b.host_out; dj.host_cap = b.host_cap;
+    }
     constexpr u64 TM = TAGGED ? (u64)(TAG_MAX - 1) : 0ull;                    // compare payloads with these bits set
     constexpr int NB = 1 << BBITS;
     constexpr int NW = THREADS / 64;
@@ -1828,7 +1846,7 @@ k_join_bkt(const RelView<NARROW> R, const RelView<NARROW> S, const JoinTask *__r
         __syncthreads();                                                     // every store / atomic of this workgroup has been issued
         if (tid == 0) {
             __threadfence_system();                                          // ... and is visible before `done` says so
-            if (atomicAdd(dj.done, 1u) == gridDim.x - 1) {                   // last workgroup of the launch
+            if (atomicAdd(dj.done, 1u) == nblocks - 1) {                     // last workgroup of the launch (BATCH: of this join)
                 __threadfence_system();
                 *dj.host_count = atomicExch(out_count, 0ull);                // publish, and leave the counters zeroed
                 *dj.done = 0;
@@ -2478,6 +2496,7 @@ static void allow_big_lds()
     SET_LDS(k_scatter_fused2<WC_THREADS_SMALL>, wc_lds_bytes(WC_MAX_BITS, WC_THREADS_SMALL));
     SET_LDS((k_join_bkt<BJ_THREADS, BJ_CHUNK, BJ_BUCKET_BITS, BJ_EPT, false>), bj_lds_bytes(BJ_THREADS, BJ_CHUNK, BJ_BUCKET_BITS));
     SET_LDS((k_join_bkt<BJ_THREADS, BJ_CHUNK, BJ_BUCKET_BITS, BJ_EPT, true>), bj_lds_bytes(BJ_THREADS, BJ_CHUNK, BJ_BUCKET_BITS));
+    SET_LDS((k_join_bkt<BJ_THREADS, BJ_CHUNK, BJ_BUCKET_BITS, BJ_EPT, true, false, false, true>), bj_lds_bytes(BJ_THREADS, BJ_CHUNK, BJ_BUCKET_BITS));
     SET_LDS((k_join_bkt<BJ_THREADS, BJ_CHUNK, BJ_BUCKET_BITS, BJ_EPT, false, true>), bj_lds_bytes(BJ_THREADS, BJ_CHUNK, BJ_BUCKET_BITS));
     SET_LDS((k_join_bkt<BJ2_THREADS, BJ2_CHUNK, BJ2_BUCKET_BITS, BJ2_EPT, false>), bj_lds_bytes(BJ2_THREADS, BJ2_CHUNK, BJ2_BUCKET_BITS));
     SET_LDS((k_join_ct<CT_THREADS, CT_CHUNK, CT_BUCKET_BITS, CT_EPT, false, false>), ct_lds_bytes());
@@ -2959,6 +2978,18 @@ void launch_join_direct(hipStream_t st, const void *d_R, u64 nR, const void *d_S
                        RelView<false>{(const Tup *)d_S}, (const JoinTask *)nullptr, (const u32 *)nullptr, 0, (Pair *)d_out,
                        out_capacity, d_out_count, dj);
 }
+
+// up to 16 direct joins in one launch: d_batch = BatchJoinDesc[njoins] in HBM, max_blocks = the largest nblocks among them
+void launch_join_batch(hipStream_t st, const BatchJoinDesc *d_batch, u32 njoins, u32 max_blocks)
+{
+    if (njoins == 0 || max_blocks == 0) return;
+    allow_big_lds();
+    hipLaunchKernelGGL((k_join_bkt<BJ_THREADS, BJ_CHUNK, BJ_BUCKET_BITS, BJ_EPT, true, false, false, true>), dim3(max_blocks, njoins),
+                       dim3(BJ_THREADS), bj_lds_bytes(BJ_THREADS, BJ_CHUNK, BJ_BUCKET_BITS), st, RelView<false>{nullptr},
+                       RelView<false>{nullptr}, (const JoinTask *)nullptr, (const u32 *)nullptr, 0, (Pair *)nullptr, (u64)0,
+                       (u64 *)nullptr, DirectJoin{}, (const u64 *)nullptr, (const u32 *)nullptr, d_batch);
+}
+u32 join_direct_tile() { return (u32)BJ_TILE; }
 
 static unsigned stream_grid(u64 n)
 {

@@ -201,6 +201,16 @@ void launch_join_direct(hipStream_t st, const void *, u64, const void *, u64, vo
 {
     fake_enqueue(st, [=] { fake_join(d_out, out_capacity, d_out_count, host_count, host_out, host_cap); });
 }
+void launch_join_batch(hipStream_t st, const BatchJoinDesc *d_batch, u32 njoins, u32)
+{
+    fake_enqueue(st, [=] {                                          // (the descriptors arrive with the staged upload)
+        for (u32 i = 0; i < njoins; i++) {
+            const BatchJoinDesc &b = d_batch[i];
+            fake_join(b.out, b.cap, b.count, b.host_count, b.host_out, b.host_cap);
+        }
+    });
+}
+u32 join_direct_tile() { return 4096; }
 void launch_checksum(hipStream_t, const void *, u64, u64 *) {}
 void launch_generate(hipStream_t, int, void *, u64, u64, u64, u64, double) {}
 void launch_expected_pkfk(hipStream_t, const void *, u64, u64 *) {}

@@ -65,6 +65,31 @@ int main()
     th.emplace_back(query_thread, 2, 5u << 20, 5u << 20, 3, 1);
     th.emplace_back(query_thread, 3, 9u << 20, 4u << 20, 2, 1);
     for (int k = 0; k < 4; k++) th.emplace_back(query_thread, 4 + k, 1500 + 700 * k, 9000 + 3000 * k, 40, 1);
+    // two callers of rhj_join_batch: 40 small joins per call (three launches of <= 16), inputs staged and pages filled by the
+    // context's helper threads
+    auto batch_thread = [&](int id) {
+        rhj_ctx *ctx = nullptr;
+        if (rhj_init(0, &ctx) != RHJ_OK) { ok = false; return; }
+        std::vector<std::vector<rhj_tuple>> rel;
+        std::vector<rhj_join_desc> joins;
+        for (int j = 0; j < 40; j++) { rel.push_back(relation(900 + 531 * j)); rel.push_back(relation(20000 + 997 * j)); }
+        for (int j = 0; j < 40; j++) joins.push_back(rhj_join_desc{rel[2 * j].data(), rel[2 * j].size(), rel[2 * j + 1].data(), rel[2 * j + 1].size()});
+        for (int r = 0; r < 6; r++) {
+            std::vector<void *> pages(joins.size());
+            std::vector<uint64_t> counts(joins.size());
+            const int rc = rhj_join_batch(ctx, (uint32_t)joins.size(), joins.data(), pages.data(), counts.data());
+            if (rc != RHJ_OK) { fprintf(stderr, "batch thread %d: rc %d: %s\n", id, rc, rhj_last_error(ctx)); ok = false; }
+            for (size_t j = 0; j < joins.size(); j++) {
+                char what[64];
+                snprintf(what, sizeof what, "batch thread %d call %d join %zu", id, r, j);
+                if (rc == RHJ_OK && (counts[j] != FAKE_PAIRS || !page_ok(pages[j], counts[j], what))) ok = false;
+                free(pages[j]);
+            }
+        }
+        rhj_destroy(ctx);
+    };
+    th.emplace_back(batch_thread, 20);
+    th.emplace_back(batch_thread, 21);
     for (std::thread &t : th) t.join();
     puts(ok ? "tsan harness: every page as expected" : "tsan harness: FAILED");
     return ok ? 0 : 1;

@@ -27,6 +27,19 @@ int main()
         if (line == "F") { if (!batches.back().empty()) batches.emplace_back(); continue; }
         batches.back().emplace_back(line);
     }
+    const char *mode = getenv("RHJ_QUERY_MODE");
+    if (mode && std::string(mode) == "batch") {
+        // one thread, one GPU context; every batch of queries level by level, the joins of a level sixteen per GPU launch
+        JobScheduler js;
+        js.init(NUM_OF_THREADS);
+        for (auto &batch : batches) Query::execute_batch(js, batch, relations);
+        js.stop();
+        js.destroy();
+        for (auto &batch : batches)
+            for (const Query &q : batch) q.print();
+        for (relList &r : relations) r.destroy();
+        return 0;
+    }
     MainScheduler ms;
     ms.init(NUM_OF_THREADS);                 // 8 query threads, each with a private JobScheduler = private GPU context
     for (auto &batch : batches)

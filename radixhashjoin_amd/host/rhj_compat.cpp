@@ -314,6 +314,23 @@ void Result::join_buckets(relation_info *small, relation_info *big, size_t begSm
 // with capacity == size == number of pairs and next == nullptr -- every consumer reads capacity/size
 // at run time (intermediate.cpp:151-179), so the invariant "head has `size` pairs, every other page
 // `capacity`" holds.
+void Result::multiRadixHashJoinBatch(JobScheduler &js, size_t n, relation *const *R, relation *const *S, Result *const *results)
+{
+    std::vector<rhj_join_desc> d(n);
+    std::vector<void *> pages(n, nullptr);
+    std::vector<uint64_t> counts(n, 0);
+    for (size_t i = 0; i < n; i++)
+        d[i] = rhj_join_desc{(const rhj_tuple *)R[i]->tuples, R[i]->num_tuples, (const rhj_tuple *)S[i]->tuples, S[i]->num_tuples};
+    const int rc = rhj_join_batch(js.context(), (uint32_t)n, d.data(), pages.data(), counts.data());
+    if (rc != RHJ_OK) die(js.context(), "rhj_join_batch", rc);
+    for (size_t i = 0; i < n; i++) {
+        if (!pages[i]) continue;                                  // head stays nullptr -> isEmpty()
+        results[i]->head = (bucket_info *)pages[i];               // next is already nullptr
+        results[i]->capacity = counts[i];
+        results[i]->size = counts[i];
+    }
+}
+
 void Result::multiRadixHashJoin(JobScheduler &js, relation &relR, relation &relS)
 {
     void *page = nullptr;

@@ -157,6 +157,10 @@ struct Result {                               /* Result.h:19-38 */
     void add_result(uint64_t keyR, uint64_t keyS);
     void addAll(bucket_info *node, size_t size);
     void multiRadixHashJoin(JobScheduler &js, relation &relR, relation &relS);
+    /* NOT in the reference: n joins in one call (rhj_join_batch, sixteen small joins per GPU launch).  results[i] must be
+       fresh Results; afterwards each is what results[i]->multiRadixHashJoin(js, *R[i], *S[i]) would have left.  Used by the
+       level-by-level query executor of rhj_query.cpp (RHJ_QUERY_MODE=batch). */
+    static void multiRadixHashJoinBatch(JobScheduler &js, size_t n, relation *const *R, relation *const *S, Result *const *results);
     void join_buckets(relation_info *small, relation_info *big, size_t begSmall, size_t begBig, size_t histSmall,
                       size_t histBig, bool orderFlag);
 private:

@@ -332,6 +332,69 @@ void Query::run_joins(JobScheduler &js, vector<relList> &relations, FilteredRows
     }
 }
 
+// Level-by-level execution of a batch of queries (see rhj_query.h).  Per query the same steps as run_filters / run_joins, the
+// join chain advanced one join per round; the joins of a round go to the GPU together.
+void Query::execute_batch(JobScheduler &js, vector<Query> &queries, vector<relList> &relations)
+{
+    struct State {
+        Query *q;
+        FilteredRows filtered;
+        vector<vector<uint64_t> > intermediate;
+        size_t next = 0;                                               // next predicate of q->join
+        bool done = false;
+    };
+    vector<State> st(queries.size());
+    for (size_t i = 0; i < queries.size(); i++) {
+        State &s = st[i];
+        s.q = &queries[i];
+        s.q->filtered_out = s.q->run_filters(relations, s.filtered);
+        s.intermediate.resize(s.q->table.size());
+        s.done = s.q->filtered_out;
+    }
+    for (;;) {
+        vector<State *> level;
+        for (State &s : st) {
+            // same-alias predicates are row filters on the host (parse_table): consume them until a real join comes up
+            while (!s.done && s.next < s.q->join.size() && s.q->join[s.next].table1 == s.q->join[s.next].table2) {
+                join_info &j = s.q->join[s.next++];
+                parse_table(j, relations[s.q->table[j.table1]], s.filtered, s.intermediate);
+                if (s.intermediate[j.table1].empty()) { s.q->filtered_out = true; s.done = true; }
+            }
+            if (!s.done && s.next < s.q->join.size()) level.push_back(&s);
+        }
+        if (level.empty()) break;
+        const size_t n = level.size();
+        vector<relation> R(n), S(n);
+        vector<Result> res(n);
+        vector<relation *> pR(n), pS(n);
+        vector<Result *> pres(n);
+        for (size_t i = 0; i < n; i++) {
+            State &s = *level[i];
+            join_info &j = s.q->join[s.next];
+            R[i].create_relation(j.table1, relations[s.q->table[j.table1]], j.column1, s.filtered, s.intermediate[j.table1]);
+            S[i].create_relation(j.table2, relations[s.q->table[j.table2]], j.column2, s.filtered, s.intermediate[j.table2]);
+            pR[i] = &R[i]; pS[i] = &S[i]; pres[i] = &res[i];
+        }
+        Result::multiRadixHashJoinBatch(js, n, pR.data(), pS.data(), pres.data());     // <-- the hot path, n joins at once
+        for (size_t i = 0; i < n; i++) {
+            State &s = *level[i];
+            log_join(R[i], S[i], res[i]);
+            if (res[i].isEmpty()) { s.q->filtered_out = true; s.done = true; continue; }
+            update_intermediate(s.intermediate, res[i], s.q->join[s.next]);
+            s.next++;
+        }
+    }
+    for (State &s : st) {
+        if (s.q->filtered_out) continue;
+        for (proj_info &p : s.q->proj) {
+            const uint64_t *col = relations[s.q->table[p.table]].values[p.column];
+            uint64_t sum = 0;
+            for (uint64_t rowid : s.intermediate[p.table]) sum += col[rowid];
+            p.sum = sum;
+        }
+    }
+}
+
 void Query::execute(JobScheduler &js, vector<relList> &relations)
 {
     // default: the whole query device-resident (rhj_query_dev.cpp); RHJ_QUERY_MODE=host keeps filters and

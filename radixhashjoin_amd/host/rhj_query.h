@@ -81,6 +81,11 @@ struct Query {                                /* Query.h:34-59 */
                    std::unordered_map<uint64_t, std::unordered_set<uint64_t> > &filtered);
     void print() const;
     std::string result_line() const;
+    /* NOT in the reference: a batch of queries executed LEVEL BY LEVEL from one thread (host mode semantics): all filters,
+       then the first join of every query in ONE Result::multiRadixHashJoinBatch call, the intermediates, the second joins ...
+       -- the joins of one level are independent, and sixteen of them share a GPU launch (rhj_join_batch).  Same results as
+       execute() per query.  (join_main: RHJ_QUERY_MODE=batch.) */
+    static void execute_batch(JobScheduler &js, std::vector<Query> &queries, std::vector<relList> &relations);
 private:
     std::string text_;
     size_t pos_ = 0;

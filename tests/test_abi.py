@@ -27,7 +27,7 @@ def test_every_declared_symbol_is_exported_and_bound():
     assert declared == set(binding.SYMBOLS), declared ^ set(binding.SYMBOLS)
     for name in declared:
         assert getattr(lib, name) is not None
-    assert lib.rhj_abi_version() == 2
+    assert lib.rhj_abi_version() == 3
 
 
 def test_layouts_match_reference_structs():

@@ -32,11 +32,11 @@ def test_three_way_join_both_modes(tmp_path, n, dup):
     work = "".join(f"0 1 2|0.1=1.0&1.1=2.0&0.2<{x}|0.0 1.2 2.2\n" for x in xs) + "F\n"
     stdin = ("".join(str(tmp_path / f"t{t}") + "\n" for t in range(3)) + "Done\n" + work).encode()
     outs = {}
-    for mode in ("host", "device"):
+    for mode in ("host", "device", "batch"):
         r = subprocess.run([JOIN], input=stdin, env=dict(os.environ, RHJ_QUERY_MODE=mode), capture_output=True,
                            check=True, timeout=600)
         outs[mode] = r.stdout.decode().splitlines()
-    assert outs["host"] == outs["device"]
+    assert outs["host"] == outs["device"] == outs["batch"]
     # independent evaluation: expand matches with numpy (value v of tX.c0 occupies rows [v*dup, (v+1)*dup))
     for x, line in zip(xs, outs["device"]):
         r0 = np.nonzero(T[0][2] < x)[0]

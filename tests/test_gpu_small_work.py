@@ -6,6 +6,7 @@ import collections
 import os
 import subprocess
 
+import numpy as np
 import pytest
 
 pytestmark = pytest.mark.gpu
@@ -41,7 +42,18 @@ def test_small_work_device_resident_queries(tmp_path):
     assert out == open(os.path.join(GOLD, "small", "small.result"), "rb").read()
 
 
-@pytest.mark.parametrize("mode", ["host", "device"])
+def test_small_work_level_batched_queries(tmp_path, small_joins):
+    """RHJ_QUERY_MODE=batch: ONE thread runs each batch of queries level by level, the joins of a level through
+    rhj_join_batch, sixteen per GPU launch.  Same 50 lines, and the same 94 joins with the same counts."""
+    out, log = run_small(tmp_path, mode="batch")
+    assert out == open(os.path.join(GOLD, "small", "small.result"), "rb").read()
+    meta, _ = small_joins
+    want = collections.Counter((c["nR"], c["nS"], c["count"]) for c in meta)
+    got = collections.Counter(tuple(int(x) for x in line.split()) for line in open(log))
+    assert sum(got.values()) == 94 and got == want
+
+
+@pytest.mark.parametrize("mode", ["host", "device", "batch"])
 def test_edge_queries_match_the_reference(mode):
     """corners of Query::run_joins that small.work never reaches: a projected alias that is never joined (sums to 0,
     Query.cpp:198-200 over an empty intermediate), two disconnected joins (the second drops the older columns,
@@ -53,3 +65,32 @@ def test_edge_queries_match_the_reference(mode):
     env = dict(os.environ, RHJ_QUERY_MODE=mode)
     out = subprocess.run([JOIN], input=stdin, cwd=GOLD, env=env, capture_output=True, timeout=600, check=True).stdout
     assert out == open(os.path.join(edge, "edge.result"), "rb").read()
+
+
+def test_join_batch_equals_the_golden_pair_sets(engine, small_joins):
+    """rhj_join_batch (sixteen small joins per launch) over the 15 small.work calls whose inputs and pairs are in
+    tests/golden/small_joins.npz, twice (the per-join device counters are left clean by the kernel), next to a join that is too
+    large for the one-launch path, an empty one and a many-to-many one whose result outgrows 32x the guess"""
+    from conftest import small_call_arrays
+    from oracle.pyoracle import TUPLE, sorted_pairs
+    meta, npz = small_joins
+    with_vectors = [i for i, c in enumerate(meta) if c.get("vectors")]
+    cases = [small_call_arrays(npz, i) for i in with_vectors]
+    rng = np.random.default_rng(4)
+    big_R = np.empty(300_000, dtype=TUPLE); big_R["key"] = np.arange(300_000); big_R["payload"] = rng.permutation(300_000)
+    big_S = np.empty(400_000, dtype=TUPLE); big_S["key"] = np.arange(400_000); big_S["payload"] = rng.integers(0, 300_000, 400_000)
+    dup_R = np.zeros(3_000, dtype=TUPLE); dup_R["key"] = np.arange(3_000); dup_R["payload"] = 7
+    dup_S = np.zeros(2_000, dtype=TUPLE); dup_S["key"] = np.arange(2_000); dup_S["payload"] = 7           # 6 * 10^6 pairs from 5000 tuples
+    empty = np.zeros(0, dtype=TUPLE)
+    joins = [(R, S) for R, S, _ in cases] + [(big_R, big_S), (empty, cases[0][1]), (dup_R, dup_S)] + [(R, S) for R, S, _ in cases[:5]]
+    for _ in range(2):
+        got = engine.join_batch(joins)
+        assert len(got) == len(joins)
+        for (R, S, P), g in zip(cases + cases[:0], got[:len(cases)]):
+            assert np.array_equal(sorted_pairs(g), sorted_pairs(P))
+        k = len(cases)
+        assert len(got[k]) == 400_000 and np.array_equal(big_R["payload"][got[k]["keyR"].astype(np.int64)], big_S["payload"][got[k]["keyS"].astype(np.int64)])
+        assert len(got[k + 1]) == 0
+        assert len(got[k + 2]) == 6_000_000 and len(np.unique(got[k + 2]["keyR"] * np.uint64(2_000) + got[k + 2]["keyS"])) == 6_000_000
+        for (R, S, P), g in zip(cases[:5], got[k + 3:]):
+            assert np.array_equal(sorted_pairs(g), sorted_pairs(P))

@@ -46,7 +46,8 @@ class RhjError(RuntimeError):
 
 
 def lib_path():
-    return os.path.join(os.path.dirname(os.path.abspath(__file__)), "librhj_hip.so")
+    """the in-tree library; RHJ_LIB_PATH names another build of it (development A/B runs: tools/ab/)"""
+    return os.environ.get("RHJ_LIB_PATH") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "librhj_hip.so")
 
 
 _LIB = None

@@ -1925,6 +1925,26 @@ __device__ __forceinline__ u32 ct_bucket(u64 key)
     return (((u32)key ^ (u32)(key >> 32)) * 0x9E3779B1u) >> (32 - BBITS);
 }
 
+// Pair stores of the fast path through a per-wavefront BUFFER DESCRIPTOR (base = the wavefront's first output slot, records =
+// what the output buffer has left from there: a pair past the capacity is dropped by the hardware's range check): a store
+// is descriptor + lane offset (mbcnt * 16) + scalar running offset, against a 64-bit address computed per lane and a
+// capacity compare + branch per store.  Round 3 tried this and got wrong pairs in 2 of 15 instantiations; the cause
+// (tools/srd_store_hazard.hip, profiles/r04_srd_store_hazard_probe.txt, [measured] on gfx950): a VALU write to the DATA registers
+// of a buffer_store_dwordx4 right behind the store races with the store's read of them --
+//     soffset an SGPR:            0 wait states 1.4 % of the pairs wrong, 1 wait state clean (LLVM inserts none: its hazard table
+//                                 exempts stores whose soffset is a register, GCNHazardRecognizer::createsVALUHazard)
+//     soffset the literal 0:      0 wait states 19 % wrong, 1 wait state STILL 1.5 % wrong (LLVM inserts exactly one)
+// -- not a range problem (bases 5 GiB into an allocation, records clamped to 2^32 - 1: clean).  So the store is issued from
+// inline assembly together with its own `s_nop 1` (two wait states), SGPR soffset.
+#ifndef RHJ_CT_SRD_STORES
+#define RHJ_CT_SRD_STORES 1
+#endif
+__device__ __forceinline__ void srd_store_pair(u64 r, u64 s_, __amdgpu_buffer_rsrc_t rsrc, u32 voff, u32 soff)
+{
+    const v4u32 d = {(u32)r, (u32)(r >> 32), (u32)s_, (u32)(s_ >> 32)};
+    asm volatile("buffer_store_dwordx4 %0, %1, %2, %3 offen\n\ts_nop 1" : : "v"(d), "v"(voff), "s"(rsrc), "s"(soff));
+}
+
 // STAMPS: tuning aid (RHJ_CT_STAMPS=1): thread 0 of the first workgroups records s_memrealtime (100 MHz) at phase
 // boundaries into `stamps` (CT_NSTAMP words per workgroup); never set in production launches.
 constexpr int CT_NSTAMP = 16;
@@ -2252,6 +2272,16 @@ k_join_ct(const RelView<NARROW> R, const RelView<NARROW> S, const JoinTask *__re
         stamp();                                                             // 8: output reserved
         if (out != nullptr && wave_total) {
             u64 o = *gres + wbase;                                           // next output slot of this wavefront
+            // narrow partitions only (SRD stores): with 64-bit rowIDs the four-register data tuples of the stores cost the 16-byte-
+            // tuple instantiations 32 more spilled VGPRs
+            constexpr bool SRD = NARROW && RHJ_CT_SRD_STORES != 0;
+            // (wave-uniform: the descriptor and the running offset live in SGPRs)
+            // (the builtin returns int: without the casts a low word >= 2^31 -- a pair index beyond 2^31, 2.15 * 10^9 pairs -- sign-extends
+            // into the high word; that, not the hazard, was what still failed the 2.2 * 10^9 checksum)
+            const u64 o_first = ((u64)(u32)__builtin_amdgcn_readfirstlane((u32)(o >> 32)) << 32) | (u64)(u32)__builtin_amdgcn_readfirstlane((u32)o);
+            const u64 o_left = out_capacity > o_first ? out_capacity - o_first : 0;
+            const __amdgpu_buffer_rsrc_t orsrc = make_srd(out + o_first, o_left > 0x0FFFFFFFull ? 0xFFFFFFF0u : (u32)o_left * 16u);
+            u32 orun = 0;                                                    // pairs this wavefront has stored so far
             // The first match of every slot: EPT independent LDS reads in flight together (one read, wait, store per slot
             // left 16 LDS round trips per thread exposed behind one another).
             Rid br0[EPT];
@@ -2270,8 +2300,13 @@ k_join_ct(const RelView<NARROW> R, const RelView<NARROW> S, const JoinTask *__re
                 u32 mask = mi[k] >> 16;
                 const unsigned long long bal = __ballot(mask != 0);
                 if (mask) {
-                    const u64 dst = o + (u64)__popcll(bal & lt);
                     mask &= mask - 1;
+                    if constexpr (SRD) {
+                    const u32 lanepos = __builtin_amdgcn_mbcnt_hi((u32)(bal >> 32), __builtin_amdgcn_mbcnt_lo((u32)bal, 0u));
+                    if (build_is_S) srd_store_pair((u64)prid[k], (u64)br0[k], orsrc, lanepos * 16u, orun * 16u);   // orderFlag, Result.cpp:64-68
+                    else            srd_store_pair((u64)br0[k], (u64)prid[k], orsrc, lanepos * 16u, orun * 16u);
+                    } else {
+                    const u64 dst = o + (u64)__popcll(bal & lt);
                     if (dst < out_capacity) {
                         Pair pr;
                         if (build_is_S) { pr.r = prid[k]; pr.s = br0[k]; }     // orderFlag, Result.cpp:64-68
@@ -2281,10 +2316,11 @@ k_join_ct(const RelView<NARROW> R, const RelView<NARROW> S, const JoinTask *__re
                         // ([measured] WRITE_SIZE 18.32 GB per 10^9 pairs against 16.03, same kernel time within 1 %)
                         out[dst] = pr;
                     }
+                    }
                     mi[k] = (mi[k] & 0xFFFFu) | (mask << 16);
                     more |= mask;
                 }
-                o += (u64)__popcll(bal);
+                if constexpr (SRD) orun += (u32)__popcll(bal); else o += (u64)__popcll(bal);
             }
             // Pass 2: further matches of a slot (duplicates on the build side), behind the first matches of the wavefront --
             // the order of the pairs is free.  Round r stores the (r+2)-th match of every lane that has one.
@@ -2296,9 +2332,15 @@ k_join_ct(const RelView<NARROW> R, const RelView<NARROW> S, const JoinTask *__re
                     u32 mask = mi[k] >> 16;
                     for (unsigned long long bal = __ballot(mask != 0); bal != 0; bal = __ballot(mask != 0)) {
                         if (mask) {
-                            const u64 dst = o + (u64)__popcll(bal & lt);
                             const u32 bpos = (u32)__ffs((int)mask) - 1;
                             mask &= mask - 1;
+                            if constexpr (SRD) {
+                            const u32 lanepos = __builtin_amdgcn_mbcnt_hi((u32)(bal >> 32), __builtin_amdgcn_mbcnt_lo((u32)bal, 0u));
+                            const u64 br = rid[lo + bpos];
+                            if (build_is_S) srd_store_pair((u64)prid[k], br, orsrc, lanepos * 16u, orun * 16u);
+                            else            srd_store_pair(br, (u64)prid[k], orsrc, lanepos * 16u, orun * 16u);
+                            } else {
+                            const u64 dst = o + (u64)__popcll(bal & lt);
                             if (dst < out_capacity) {
                                 const u64 br = rid[lo + bpos];
                                 Pair pr;
@@ -2306,8 +2348,9 @@ k_join_ct(const RelView<NARROW> R, const RelView<NARROW> S, const JoinTask *__re
                                 else            { pr.r = br; pr.s = prid[k]; }
                                 out[dst] = pr;
                             }
+                            }
                         }
-                        o += (u64)__popcll(bal);
+                        if constexpr (SRD) orun += (u32)__popcll(bal); else o += (u64)__popcll(bal);
                     }
                 }
             }

@@ -242,6 +242,22 @@ int rhj_shard_stats(rhj_ctx *ctx, int side, const rhj_tuple *d_rel, uint64_t n, 
  * reported by the rhj_shard_join of this context: RHJ_E_INVALID). */
 int rhj_shard_split(rhj_ctx *ctx, int side, const rhj_tuple *d_rel, uint64_t n, int shift, int bits, uint64_t key_base,
                     void *d_narrow_out, uint64_t *d_class_start);
+/* rhj_shard_split with NO send buffer and NO all-to-all: class c of this rank's shard is written straight into the receive
+ * arrays of the rank that owns it -- peer_payloads[owner[c]] (uint64) / peer_rowids[owner[c]] (uint32), device pointers of
+ * this process: a peer's HBM opened with rhj_ipc_open (xGMI peer stores), or local buffers -- starting at element
+ * dst_class_start[c] of those arrays (from the gathered count matrix: where sender `rank`'s segment begins in the owner's
+ * arrays + the sender's classes of that owner before c).  owner / dst_class_start: HOST arrays of 2^bits entries.
+ * Same d_rel / n / shift / bits / key_base rules as rhj_shard_split; the receiver must not read its arrays before every
+ * sender's call has completed (a barrier on the stream, e.g. a 1-word all-reduce), then runs rhj_shard_partition as usual.
+ * HBM traffic per tuple: 16 B read + 12 B written, against + 12 B read + 12 B written by the all-to-all's copy. */
+int rhj_shard_split_peer(rhj_ctx *ctx, int side, const rhj_tuple *d_rel, uint64_t n, int shift, int bits, uint64_t key_base,
+                         const uint8_t *owner, const uint64_t *dst_class_start, void *const *peer_payloads, void *const *peer_rowids,
+                         int nranks);
+/* HBM of another process of the node mapped into this one (hipIpc*): export a 64-byte handle of a device allocation, open it
+ * elsewhere, close it.  For the peer arrays of rhj_shard_split_peer.  Unverified on the one-GPU boxes of this pool. */
+int rhj_ipc_export(rhj_ctx *ctx, void *d_ptr, void *handle64);
+int rhj_ipc_open(rhj_ctx *ctx, const void *handle64, void **d_ptr);
+int rhj_ipc_close(rhj_ctx *ctx, void *d_ptr);
 /* asynchronous; seg_off: HOST array of nseg + 1 offsets into the received arrays (seg_off[0] = 0, seg_off[nseg] = m),
  * segment s = what rank s sent; row0: HOST array of nseg rowID bases (the key_base each rank split this relation with);
  * plan: the resolved two-pass plan rhj_shard_plan returned a mode for; plan and mode the same on both sides */

@@ -88,6 +88,10 @@ SYMBOLS = {
     "rhj_shard_plan": (C.c_int, [_u64, _u64, _P(Opts), _P(Opts)]),
     "rhj_shard_stats": (C.c_int, [_vp, C.c_int, _vp, _u64, C.c_int, C.c_int, _vp, _P(_u64), _P(_u64)]),
     "rhj_shard_split": (C.c_int, [_vp, C.c_int, _vp, _u64, C.c_int, C.c_int, _u64, _vp, _vp]),
+    "rhj_shard_split_peer": (C.c_int, [_vp, C.c_int, _vp, _u64, C.c_int, C.c_int, _u64, _vp, _vp, _vp, _vp, C.c_int]),
+    "rhj_ipc_export": (C.c_int, [_vp, _vp, _vp]),
+    "rhj_ipc_open": (C.c_int, [_vp, _vp, _P(_vp)]),
+    "rhj_ipc_close": (C.c_int, [_vp, _vp]),
     "rhj_shard_partition": (C.c_int, [_vp, C.c_int, _vp, _vp, _u64, C.c_int, _vp, _vp, _P(Opts), C.c_int]),
     "rhj_shard_join": (C.c_int, [_vp, _vp, _u64, _P(_u64)]),
     "rhj_pairs_checksum_dev": (C.c_int, [_vp, _vp, _u64, _P(_u64)]),
@@ -423,6 +427,17 @@ class Engine:
     def shard_split(self, side, d_rel, n, shift, bits, key_base, d_narrow_out, d_class_start=None):
         self._chk(self.lib.rhj_shard_split(self.ctx, side, _addr(d_rel), n, shift, bits, key_base, _addr(d_narrow_out),
                                            _addr(d_class_start)))
+
+    def shard_split_peer(self, side, d_rel, n, shift, bits, key_base, owner, dst_class_start, peer_payloads, peer_rowids):
+        """rhj_shard_split_peer: owner (uint8[2^bits]) and dst_class_start (uint64[2^bits]) numpy arrays, peer_* lists of device
+        pointers / buffers, one per rank"""
+        owner = np.ascontiguousarray(owner, dtype=np.uint8)
+        dst = np.ascontiguousarray(dst_class_start, dtype=np.uint64)
+        nr = len(peer_payloads)
+        pp = (_vp * nr)(*[_addr(x) for x in peer_payloads])
+        pk = (_vp * nr)(*[_addr(x) for x in peer_rowids])
+        self._chk(self.lib.rhj_shard_split_peer(self.ctx, side, _addr(d_rel), n, shift, bits, key_base, owner.ctypes.data, dst.ctypes.data,
+                                                pp, pk, nr))
 
     def shard_partition(self, side, d_payloads, d_rowids, m, seg_off, row0, plan, mode):
         assert len(row0) == len(seg_off) - 1

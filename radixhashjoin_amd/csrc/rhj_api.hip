@@ -192,6 +192,8 @@ struct rhj_ctx {
     bool fuse_clean = false;           // ... which the kernels leave zeroed (false: the next call clears them first)
     u64 *h_pub = nullptr, *h_pub_dev = nullptr;   // pinned: the join counters as the bucket join's last workgroup publishes them
     int opt_fused = -1;                // -1: automatic (RHJ_FUSE env, default 1), 0 / 1
+    std::vector<u64> shard_ps_host[2]; // the class boundaries of the last rhj_shard_stats of each side (host copy)
+    DevBuf shard_peer_tab;             // rhj_shard_split_peer: delta[2^bits] u64 + owner[2^bits] u8 per side
     DevBuf shard_wide;                 // u32 per side: rhj_shard_split met a rowID - key_base >= 2^32 (checked by rhj_shard_join)
     // rhj_dev_alloc / rhj_dev_free keep released blocks for re-use (all work of a context is ordered on its one
     // stream, so a block may be handed out again while kernels that used it are still queued): a device-resident
@@ -1271,7 +1273,7 @@ int rhj_release_workspace(rhj_ctx *ctx)
                      &ctx->unit_start_b, &ctx->unit_hist_b, &ctx->unit_base_b, &ctx->scan_tmp_b, &ctx->tasks,
                      &ctx->counters, &ctx->out_pairs, &ctx->small_out, &ctx->hist_tmp, &ctx->scan_tmp, &ctx->hist2,
                      &ctx->grp_rng, &ctx->unit_start2, &ctx->narrow_flag, &ctx->seg_rng, &ctx->tag_base,
-                     &ctx->shard_ps[0], &ctx->shard_ps[1], &ctx->shard_mm, &ctx->shard_wide, &ctx->fuse_ctl, &ctx->b_in[0], &ctx->b_out[0], &ctx->b_cnt[0],
+                     &ctx->shard_ps[0], &ctx->shard_ps[1], &ctx->shard_mm, &ctx->shard_wide, &ctx->shard_peer_tab, &ctx->fuse_ctl, &ctx->b_in[0], &ctx->b_out[0], &ctx->b_cnt[0],
                      &ctx->b_in[1], &ctx->b_out[1], &ctx->b_cnt[1]};
     ctx->fuse_clean = false;
     for (DevBuf *b : all) release(*b);
@@ -2258,6 +2260,7 @@ int rhj_shard_stats(rhj_ctx *ctx, int side, const rhj_tuple *d_rel, uint64_t n, 
     HIPCHK(ctx, hipMemcpyAsync(hmm, mm, 16, hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     for (size_t b = 0; b < nbins; b++) hist[b] = n ? ps[b + 1] - ps[b] : 0;
+    ctx->shard_ps_host[side] = ps;
     if (key_min) *key_min = n ? hmm[0] : 0;
     if (key_max) *key_max = n ? hmm[1] : 0;
     ctx->shard_n[side] = n;
@@ -2293,6 +2296,80 @@ int rhj_shard_split(rhj_ctx *ctx, int side, const rhj_tuple *d_rel, uint64_t n, 
     if (d_class_start)
         HIPCHK(ctx, hipMemcpyAsync(d_class_start, ctx->shard_ps[side].p, (nbins + 1) * 8, hipMemcpyDeviceToDevice, ctx->stream));
     return check_launch(ctx, "rhj_shard_split");
+}
+
+// The class split of rhj_shard_split written STRAIGHT INTO THE OWNERS' RECEIVE ARRAYS (peer-mapped HBM over xGMI; on one GPU:
+// any device buffers), instead of into a local send buffer that an all-to-all then copies.
+int rhj_shard_split_peer(rhj_ctx *ctx, int side, const rhj_tuple *d_rel, uint64_t n, int shift, int bits, uint64_t key_base,
+                         const uint8_t *owner, const uint64_t *dst_class_start, void *const *peer_payloads, void *const *peer_rowids,
+                         int nranks)
+{
+    RHJCHK(use_device(ctx));
+    if ((side != 0 && side != 1) || bits < 1 || bits > 8 || shift < 0 || shift + bits > 64 || (n && !d_rel) || !owner || !dst_class_start ||
+        !peer_payloads || !peer_rowids || nranks < 1 || nranks > seg_max())
+        return fail(ctx, RHJ_E_INVALID, "bad rhj_shard_split_peer argument");
+    const size_t nbins = (size_t)1 << bits;
+    if (ctx->shard_n[side] != n || ctx->shard_ps_host[side].size() != nbins + 1)
+        return fail(ctx, RHJ_E_INVALID, "rhj_shard_split_peer: call rhj_shard_stats for this side and relation first");
+    if (n && (key_base > ctx->shard_kmin[side] || ctx->shard_kmax[side] - key_base >= ((u64)1 << 32)))
+        return fail(ctx, RHJ_E_INVALID, "rhj_shard_split_peer: rowID - key_base must lie in [0, 2^32) for every tuple of the shard");
+    for (size_t c = 0; c < nbins; c++)
+        if (owner[c] >= nranks || !peer_payloads[owner[c]] || !peer_rowids[owner[c]])
+            return fail(ctx, RHJ_E_INVALID, "rhj_shard_split_peer: a class is owned by a rank without receive arrays");
+    prof_reset(ctx);
+    const ShardTables t = shard_tables(ctx, side);
+    PassGeom g = make_geom(n, 1, shift, bits);
+    g.mix = MIX_STORE;
+    // delta[c] = (index of this rank's class c in its owner's arrays) - (index it would have in a local send buffer)
+    const size_t tab_bytes = nbins * 8 + nbins;
+    RHJCHK(ensure(ctx, ctx->shard_peer_tab, 2 * ((tab_bytes + 255) & ~(size_t)255)));
+    unsigned char *d_tab = (unsigned char *)ctx->shard_peer_tab.p + (size_t)side * ((tab_bytes + 255) & ~(size_t)255);
+    std::vector<unsigned char> tab(tab_bytes);
+    for (size_t c = 0; c < nbins; c++) {
+        const u64 d = dst_class_start[c] - ctx->shard_ps_host[side][c];          // (mod 2^64: added to the cursors, wraps back)
+        memcpy(&tab[c * 8], &d, 8);
+        tab[nbins * 8 + c] = owner[c];
+    }
+    // (a synchronous copy: the table is a stack object of this call)
+    HIPCHK(ctx, hipMemcpyAsync(d_tab, tab.data(), tab_bytes, hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    {
+        Span s(ctx, RHJ_K_SCATTER);
+        launch_scatter_units_narrow_peer(ctx->stream, d_rel, g, (const u64 *)t.seg0->p, (const u32 *)t.unit_start->p,
+                                         (const u64 *)t.unit_base->p, (u32 *)ctx->shard_wide.p + side, key_base, (const u64 *)d_tab,
+                                         d_tab + nbins * 8, peer_payloads, peer_rowids, nranks);
+    }
+    return check_launch(ctx, "rhj_shard_split_peer");
+}
+
+// Peer mapping of HBM between the processes of one node (one process per GPU): the owner of a receive array exports a handle,
+// the senders open it and pass the resulting pointer to rhj_shard_split_peer.  Thin wrappers over hipIpc*; UNVERIFIED on this
+// pool (one GPU per box: there is no second process with a GPU to open a handle in).
+int rhj_ipc_export(rhj_ctx *ctx, void *d_ptr, void *handle64)
+{
+    RHJCHK(use_device(ctx));
+    static_assert(sizeof(hipIpcMemHandle_t) == 64, "handle size");
+    if (!d_ptr || !handle64) return fail(ctx, RHJ_E_INVALID, "bad rhj_ipc_export argument");
+    HIPCHK(ctx, hipIpcGetMemHandle((hipIpcMemHandle_t *)handle64, d_ptr));
+    return RHJ_OK;
+}
+
+int rhj_ipc_open(rhj_ctx *ctx, const void *handle64, void **d_ptr)
+{
+    RHJCHK(use_device(ctx));
+    if (!d_ptr || !handle64) return fail(ctx, RHJ_E_INVALID, "bad rhj_ipc_open argument");
+    hipIpcMemHandle_t h;
+    memcpy(&h, handle64, sizeof h);
+    HIPCHK(ctx, hipIpcOpenMemHandle(d_ptr, h, hipIpcMemLazyEnablePeerAccess));
+    return RHJ_OK;
+}
+
+int rhj_ipc_close(rhj_ctx *ctx, void *d_ptr)
+{
+    RHJCHK(use_device(ctx));
+    if (!d_ptr) return RHJ_OK;
+    HIPCHK(ctx, hipIpcCloseMemHandle(d_ptr));
+    return RHJ_OK;
 }
 
 int rhj_shard_partition(rhj_ctx *ctx, int side, const uint64_t *d_payloads, const uint32_t *d_rowids, uint64_t m, int nseg,

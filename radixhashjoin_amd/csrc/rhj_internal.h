@@ -166,6 +166,10 @@ void launch_scatter_units_narrow_any(hipStream_t st, const void *d_in, const u32
 void launch_scatter_units_narrow(hipStream_t st, const void *d_in, void *d_out, u64 n, const PassGeom &g,
                                  const u64 *d_seg_start, const u32 *d_unit_start, const u64 *d_unit_base, u32 *d_overflow,
                                  u64 key_base = 0);
+void launch_scatter_units_narrow_peer(hipStream_t st, const void *d_in, const PassGeom &g, const u64 *d_seg_start,
+                                      const u32 *d_unit_start, const u64 *d_unit_base, u32 *d_overflow, u64 key_base,
+                                      const u64 *d_delta, const unsigned char *d_owner, void *const *peersP, void *const *peersK,
+                                      int nranks);
 void launch_scatter_ranges_narrow(hipStream_t st, const void *d_in, bool in_narrow, void *d_out, u64 n, u32 nunits, int shift,
                                   int bits, const u64 *d_unit_base, const u64 *d_rng, u32 *d_overflow, u32 tag_groups = 0,
                                   u32 tag_div = 0, const u32 *d_inK = nullptr);   // d_inK: narrow input whose rowID array is not at narrow_k_offset(n)

@@ -1148,14 +1148,27 @@ constexpr int WN9_THREADS = 896, WN9_TPT = 4, WN9_GR = 16, WN9_MAX_BITS = 9;   /
 //   low tag.bits bits of a payload -- constant inside the partition from here on, hence dead -- are replaced by that
 //   sender number, which the join kernels turn back into a global rowID (row0[sender] + local rowID).
 
-template <bool IN_NARROW, int GR_ = WN_GR, int TPT_ = WN_TPT, int THREADS_ = WN_THREADS>
+// PEER (multi-GPU sender, rhj_shard_split_peer): digit d's tuples go straight into the receive arrays of the rank that owns
+// class d -- peer.P[owner[d]] / peer.K[owner[d]], the peers' HBM mapped into this process -- at the index the receiver's
+// layout gives them: the unit cursors are moved by delta[d] = (where this sender's class d starts in its owner's arrays) -
+// (where it starts in a local send buffer), so every index below is an index into the OWNER's arrays and the carry lines
+// are aligned to the owner's 128-byte lines.  No send buffer, no all-to-all: 12 B written and 12 B read per tuple less.
+struct WnPeer {
+    const u64 *delta;            // [nbins] (device)
+    const unsigned char *owner;  // [nbins] (device): destination rank of every class
+    u64 *P[SEG_MAX];             // payload arrays of the ranks
+    u32 *K[SEG_MAX];             // rowID arrays of the ranks
+};
+
+template <bool IN_NARROW, int GR_ = WN_GR, int TPT_ = WN_TPT, int THREADS_ = WN_THREADS, bool PEER = false>
 __global__ void __launch_bounds__(THREADS_)
 k_scatter_wcn(const Tup *__restrict__ in, const u64 *__restrict__ inP, const u32 *__restrict__ inK,
               u64 *__restrict__ outP, u32 *__restrict__ outK, const u64 *__restrict__ seg_start,
               const u32 *__restrict__ unit_start, u32 nseg, u64 L, int shift, int bits,
               const u64 *__restrict__ unit_base, const u64 *__restrict__ unit_rng, u32 n_rng_units,
-              u32 *__restrict__ overflow, u64 key_base, WnTag tag, int mix)
+              u32 *__restrict__ overflow, u64 key_base, WnTag tag, int mix, WnPeer peer)
 {
+    static_assert(!PEER || !IN_NARROW, "the peer split reads the rank's own 16-byte shard");
     // a rowID that does not fit 32 bits has been seen (by the histogram kernel or by an earlier workgroup of this pass):
     // the join is going to repeat itself in the 16-byte format, nothing written from here on will be read
     if (overflow != nullptr && __builtin_nontemporal_load(overflow) != 0) return;
@@ -1175,6 +1188,9 @@ k_scatter_wcn(const Tup *__restrict__ in, const u64 *__restrict__ inP, const u32
     u32 *T = LO + nbins;                                                     // staged slots below T[d] are whole lines of digit d
     u32 *mtot = T + nbins;
     u32 *wsc = mtot + 4;
+    u32 *own = wsc + THREADS / 64;                                           // PEER: owner rank of every digit
+    u64 **pP = reinterpret_cast<u64 **>((reinterpret_cast<uintptr_t>(own + (PEER ? nbins : 0)) + 7) & ~(uintptr_t)7);   // PEER: the ranks' arrays
+    u32 **pK = reinterpret_cast<u32 **>(pP + (PEER ? SEG_MAX : 0));
 
     const u32 u = blockIdx.x;
     u64 beg, end;
@@ -1192,9 +1208,16 @@ k_scatter_wcn(const Tup *__restrict__ in, const u64 *__restrict__ inP, const u32
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const u64 tag_keep = ~(((u64)1 << tag.bits) - 1);                        // tag.bits == 0: keeps every bit
     const u64 tag_or = tag.bits ? (u64)((u % tag.ngroups) / tag.div) : 0ull;
+    if constexpr (PEER) {
+        for (u32 b = tid; b < nbins; b += THREADS) own[b] = peer.owner[b];
+        if (tid < SEG_MAX) { pP[tid] = peer.P[tid]; pK[tid] = peer.K[tid]; }
+    }
+    // where digit d's tuples are written: the one output relation, or the arrays of the rank that owns class d
+    auto dstP = [&](u32 d) -> u64 * { if constexpr (PEER) return pP[own[d]]; else return outP; };
+    auto dstK = [&](u32 d) -> u32 * { if constexpr (PEER) return pK[own[d]]; else return outK; };
 
     for (u32 b = tid; b < nbins; b += THREADS) {
-        const u64 g = unit_base[(u64)u * nbins + b];
+        const u64 g = unit_base[(u64)u * nbins + b] + (PEER ? peer.delta[b] : 0ull);
         gnext[b] = g;
         LO[b] = (u32)(g & GM);
         cnt[b] = 0;
@@ -1276,8 +1299,8 @@ k_scatter_wcn(const Tup *__restrict__ in, const u64 *__restrict__ inP, const u32
             const u64 x = LB[d];
             if (x != ~0ull && j >= (u32)(x & GM)) {
                 const u64 o = (x & ~GM) + j;
-                __builtin_nontemporal_store(sp[TILE + q], &outP[o]);
-                __builtin_nontemporal_store(sk[TILE + q], &outK[o]);
+                __builtin_nontemporal_store(sp[TILE + q], &dstP(d)[o]);
+                __builtin_nontemporal_store(sk[TILE + q], &dstK(d)[o]);
             }
         }
         const u32 mt = *mtot;
@@ -1288,7 +1311,7 @@ k_scatter_wcn(const Tup *__restrict__ in, const u64 *__restrict__ inP, const u32
             if (i < mt) {
                 const u64 v = sp[i];
                 const u32 d = (u32)(v >> shift) & mask;
-                if (i < T[d]) { const u64 o = A[d] + i; __builtin_nontemporal_store(v, &outP[o]); __builtin_nontemporal_store(sk[i], &outK[o]); }      // whole lines [a, b)
+                if (i < T[d]) { const u64 o = A[d] + i; __builtin_nontemporal_store(v, &dstP(d)[o]); __builtin_nontemporal_store(sk[i], &dstK(d)[o]); }      // whole lines [a, b)
                 else keep |= 1u << k;                                                       // tail [b, e): carried on
             }
         }
@@ -1331,8 +1354,8 @@ k_scatter_wcn(const Tup *__restrict__ in, const u64 *__restrict__ inP, const u32
         const u64 g = gnext[d];
         if (j >= LO[d] && j < (u32)(g & GM)) {
             const u64 o = (g & ~GM) + j;
-            __builtin_nontemporal_store(sp[TILE + q], &outP[o]);
-            __builtin_nontemporal_store(sk[TILE + q], &outK[o]);
+            __builtin_nontemporal_store(sp[TILE + q], &dstP(d)[o]);
+            __builtin_nontemporal_store(sk[TILE + q], &dstK(d)[o]);
         }
     }
     if constexpr (!IN_NARROW) {
@@ -2455,10 +2478,11 @@ static size_t wc_lds_bytes(int bits, int threads)
     return (size_t)threads * WC_TPT * 16 + nbins * (128 + 8 + 8 + 8 + 4 + 4 + 4 + 4) + 16 + (size_t)(threads / 64) * 4;
 }
 
-static size_t wn_lds_bytes(int bits, int gr = WN_GR, int tpt = WN_TPT, int threads = WN_THREADS)
+static size_t wn_lds_bytes(int bits, int gr = WN_GR, int tpt = WN_TPT, int threads = WN_THREADS, bool peer = false)
 {
     const size_t nbins = (size_t)1 << bits;
-    return ((size_t)threads * tpt + nbins * gr) * 12 + nbins * (8 + 8 + 8 + 4 + 4 + 4 + 4) + 16 + (size_t)(threads / 64) * 4;
+    return ((size_t)threads * tpt + nbins * gr) * 12 + nbins * (8 + 8 + 8 + 4 + 4 + 4 + 4) + 16 + (size_t)(threads / 64) * 4 +
+           (peer ? nbins * 4 + 8 + (size_t)SEG_MAX * 16 : 0);
 }
 
 static int wc_threads_for(int bits)
@@ -2562,6 +2586,7 @@ static void allow_big_lds()
     SET_LDS(k_scatter_wc_n<WC_THREADS_SMALL>, wc_lds_bytes(WC_MAX_BITS, WC_THREADS_SMALL));
     SET_LDS(k_scatter_wcn<false>, wn_lds_bytes(WN_MAX_BITS));
     SET_LDS(k_scatter_wcn<true>, wn_lds_bytes(WN_MAX_BITS));
+    SET_LDS((k_scatter_wcn<false, WN_GR, WN_TPT, WN_THREADS, true>), wn_lds_bytes(WN_MAX_BITS, WN_GR, WN_TPT, WN_THREADS, true));
     SET_LDS((k_scatter_wcn<false, WN9_GR, WN9_TPT, WN9_THREADS>), wn_lds_bytes(WN9_MAX_BITS, WN9_GR, WN9_TPT, WN9_THREADS));
     SET_LDS((k_scatter_wcn<true, WN9_GR, WN9_TPT, WN9_THREADS>), wn_lds_bytes(WN9_MAX_BITS, WN9_GR, WN9_TPT, WN9_THREADS));
     });
@@ -2807,7 +2832,26 @@ void launch_scatter_units_narrow(hipStream_t st, const void *d_in, void *d_out, 
     hipLaunchKernelGGL(k_scatter_wcn<false>, dim3(g.max_units), dim3(WN_THREADS), wn_lds_bytes(g.bits), st, (const Tup *)d_in,
                        (const u64 *)nullptr, (const u32 *)nullptr, (u64 *)d_out,
                        (u32 *)((unsigned char *)d_out + narrow_k_offset(n)), d_seg_start, d_unit_start, g.nseg, g.L, g.shift,
-                       g.bits, d_unit_base, (const u64 *)nullptr, 0u, d_overflow, key_base, WnTag{1u, 1u, 0u}, g.mix);
+                       g.bits, d_unit_base, (const u64 *)nullptr, 0u, d_overflow, key_base, WnTag{1u, 1u, 0u}, g.mix, WnPeer{});
+}
+
+// the multi-GPU sender's class split straight into the owners' receive arrays (k_scatter_wcn<.., PEER>): d_delta / d_owner:
+// 2^bits entries on the device; peersP / peersK: nranks device pointers (this rank's own arrays among them)
+void launch_scatter_units_narrow_peer(hipStream_t st, const void *d_in, const PassGeom &g, const u64 *d_seg_start,
+                                      const u32 *d_unit_start, const u64 *d_unit_base, u32 *d_overflow, u64 key_base,
+                                      const u64 *d_delta, const unsigned char *d_owner, void *const *peersP, void *const *peersK,
+                                      int nranks)
+{
+    if (g.max_units == 0) return;
+    allow_big_lds();
+    WnPeer peer{};
+    peer.delta = d_delta;
+    peer.owner = d_owner;
+    for (int i = 0; i < nranks && i < SEG_MAX; i++) { peer.P[i] = (u64 *)peersP[i]; peer.K[i] = (u32 *)peersK[i]; }
+    hipLaunchKernelGGL((k_scatter_wcn<false, WN_GR, WN_TPT, WN_THREADS, true>), dim3(g.max_units), dim3(WN_THREADS),
+                       wn_lds_bytes(g.bits, WN_GR, WN_TPT, WN_THREADS, true), st, (const Tup *)d_in, (const u64 *)nullptr,
+                       (const u32 *)nullptr, (u64 *)nullptr, (u32 *)nullptr, d_seg_start, d_unit_start, g.nseg, g.L, g.shift, g.bits,
+                       d_unit_base, (const u64 *)nullptr, 0u, d_overflow, key_base, WnTag{1u, 1u, 0u}, g.mix, peer);
 }
 
 // One narrow-output pass over segments cut into units (run_pass form): 16-byte or narrow input, <= 8 bits (32-tuple lines)
@@ -2820,7 +2864,7 @@ void launch_scatter_units_narrow_any(hipStream_t st, const void *d_in, const u32
     const bool in_narrow = d_inK != nullptr;
     const WnTag notag{1u, 1u, 0u};
 #define WCN_ARGS (const Tup *)(in_narrow ? nullptr : d_in), (const u64 *)(in_narrow ? d_in : nullptr), d_inK, (u64 *)d_outP, d_outK,    \
-                 d_seg_start, d_unit_start, g.nseg, g.L, g.shift, g.bits, d_unit_base, (const u64 *)nullptr, 0u, d_overflow, (u64)0, notag, g.mix
+                 d_seg_start, d_unit_start, g.nseg, g.L, g.shift, g.bits, d_unit_base, (const u64 *)nullptr, 0u, d_overflow, (u64)0, notag, g.mix, WnPeer{}
     if (g.bits <= WN_MAX_BITS) {
         if (in_narrow) hipLaunchKernelGGL(k_scatter_wcn<true>, dim3(g.max_units), dim3(WN_THREADS), wn_lds_bytes(g.bits), st, WCN_ARGS);
         else hipLaunchKernelGGL(k_scatter_wcn<false>, dim3(g.max_units), dim3(WN_THREADS), wn_lds_bytes(g.bits), st, WCN_ARGS);
@@ -2847,11 +2891,11 @@ void launch_scatter_ranges_narrow(hipStream_t st, const void *d_in, bool in_narr
         hipLaunchKernelGGL(k_scatter_wcn<true>, dim3(nunits), dim3(WN_THREADS), wn_lds_bytes(bits), st, (const Tup *)nullptr,
                            (const u64 *)d_in, d_inK ? d_inK : (const u32 *)((const unsigned char *)d_in + narrow_k_offset(n)), oP, oK,
                            (const u64 *)nullptr, (const u32 *)nullptr, 0u, (u64)0, shift, bits, d_unit_base, d_rng, nunits,
-                           d_overflow, (u64)0, tag, 0);
+                           d_overflow, (u64)0, tag, 0, WnPeer{});
     else
         hipLaunchKernelGGL(k_scatter_wcn<false>, dim3(nunits), dim3(WN_THREADS), wn_lds_bytes(bits), st, (const Tup *)d_in,
                            (const u64 *)nullptr, (const u32 *)nullptr, oP, oK, (const u64 *)nullptr, (const u32 *)nullptr, 0u,
-                           (u64)0, shift, bits, d_unit_base, d_rng, nunits, d_overflow, (u64)0, tag, 0);
+                           (u64)0, shift, bits, d_unit_base, d_rng, nunits, d_overflow, (u64)0, tag, 0, WnPeer{});
 }
 int tag_bits() { return (int)TAG_BITS; }
 

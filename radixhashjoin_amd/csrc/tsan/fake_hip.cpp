@@ -72,6 +72,9 @@ struct FakeEvent {
     unsigned long long recorded = 0, done = 0;
 };
 
+hipError_t hipIpcGetMemHandle(hipIpcMemHandle_t *h, void *p) { memcpy(h->reserved, &p, sizeof p); return hipSuccess; }
+hipError_t hipIpcOpenMemHandle(void **p, hipIpcMemHandle_t h, unsigned) { memcpy(p, h.reserved, sizeof *p); return hipSuccess; }
+hipError_t hipIpcCloseMemHandle(void *) { return hipSuccess; }
 hipError_t hipGetLastError() { return hipSuccess; }
 const char *hipGetErrorString(hipError_t e) { return e == hipSuccess ? "success" : "fake hip error"; }
 hipError_t hipSetDevice(int) { return hipSuccess; }
@@ -231,5 +234,7 @@ void launch_scatter_units_narrow(hipStream_t, const void *, void *, u64, const P
                                  u64) {}
 void launch_scatter_ranges_narrow(hipStream_t, const void *, bool, void *, u64, u32, int, int, const u64 *, const u64 *, u32 *, u32, u32,
                                   const u32 *) {}
+void launch_scatter_units_narrow_peer(hipStream_t, const void *, const PassGeom &, const u64 *, const u32 *, const u64 *, u32 *, u64,
+                                      const u64 *, const unsigned char *, void *const *, void *const *, int) {}
 void launch_scatter_ranges_n2a(hipStream_t, const void *, void *, u64, u32, int, int, const u64 *, const u64 *, const u64 *, u32, u32,
                                const u32 *) {}

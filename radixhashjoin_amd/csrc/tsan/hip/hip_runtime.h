@@ -23,6 +23,11 @@ struct FakeEvent;
 typedef FakeStream *hipStream_t;
 typedef FakeEvent *hipEvent_t;
 
+struct hipIpcMemHandle_t { char reserved[64]; };
+enum { hipIpcMemLazyEnablePeerAccess = 1 };
+hipError_t hipIpcGetMemHandle(hipIpcMemHandle_t *h, void *p);
+hipError_t hipIpcOpenMemHandle(void **p, hipIpcMemHandle_t h, unsigned flags);
+hipError_t hipIpcCloseMemHandle(void *p);
 hipError_t hipGetLastError();
 const char *hipGetErrorString(hipError_t e);
 hipError_t hipSetDevice(int dev);

@@ -67,6 +67,10 @@ int main(int argc, char **argv)
     if (world < 1 || world > 16 || rank < 0 || rank >= world) { fprintf(stderr, "1 <= world <= 16\n"); return 1; }
     const uint64_t MAX_MSG = env_u64("RHJ_SHARD_MAX_MSG", (uint64_t)64 << 20);
     const bool via_self = env_u64("RHJ_SHARD_VIA_SELF", 0) != 0;
+    // RHJ_SHARD_PEER=1: no send buffers and no all-to-all -- every rank's class split stores straight into the owners' receive
+    // arrays (rhj_shard_split_peer), the peers' HBM mapped with hipIpc handles exchanged by an all-gather.  With one rank the
+    // "peer" is the rank's own array (what a one-GPU box can execute); the IPC leg is unverified on this pool.
+    const bool peer_mode = env_u64("RHJ_SHARD_PEER", 0) != 0;
     if (MAX_MSG == 0) { fprintf(stderr, "RHJ_SHARD_MAX_MSG must be positive\n"); return 1; }
     uint64_t messages = 0;                                // ncclSend calls issued by this rank
     int ndev = 0;
@@ -160,7 +164,53 @@ int main(int argc, char **argv)
     void *sendbuf[2], *rP[2], *rK[2];
     uint64_t m[2], seg[2][17];
     const void *rel_in[2] = {dR, dS};
-    for (int rel = 0; rel < 2; rel++) {
+    if (peer_mode) {
+        uint8_t owner[256];
+        for (int d = 0; d < world; d++) for (int c = cuts[d]; c < cuts[d + 1]; c++) owner[c] = (uint8_t)d;
+        for (int rel = 0; rel < 2; rel++) {
+            seg[rel][0] = 0;
+            for (int r = 0; r < world; r++) seg[rel][r + 1] = seg[rel][r] + recv[rel][r];
+            m[rel] = seg[rel][world];
+            RHJOK(ctx, rhj_dev_alloc(ctx, (m[rel] + 2) * 8, &rP[rel]));
+            RHJOK(ctx, rhj_dev_alloc(ctx, (m[rel] + 4) * 4, &rK[rel]));
+            // where my classes start in every owner's arrays: behind the segments of the senders before me
+            uint64_t dst[256];
+            for (int d = 0; d < world; d++) {
+                uint64_t at = 0;
+                for (int r = 0; r < rank; r++) for (int c = cuts[d]; c < cuts[d + 1]; c++) at += H(r, rel, c);
+                for (int c = cuts[d]; c < cuts[d + 1]; c++) { dst[c] = at; at += H(rank, rel, c); }
+            }
+            // the owners' arrays, mapped into this process
+            std::vector<void *> pP(world), pK(world);
+            pP[rank] = rP[rel];
+            pK[rank] = rK[rel];
+            if (world > 1) {
+                unsigned char mine2[128], *d_h, *d_hall;
+                RHJOK(ctx, rhj_ipc_export(ctx, rP[rel], mine2));
+                RHJOK(ctx, rhj_ipc_export(ctx, rK[rel], mine2 + 64));
+                RHJOK(ctx, rhj_dev_alloc(ctx, 128, (void **)&d_h));
+                RHJOK(ctx, rhj_dev_alloc(ctx, 128 * (size_t)world, (void **)&d_hall));
+                RHJOK(ctx, rhj_copy_h2d(ctx, d_h, mine2, 128));
+                NCCLOK(ncclAllGather(d_h, d_hall, 128, ncclUint8, comm, st));
+                std::vector<unsigned char> allh(128 * (size_t)world);
+                RHJOK(ctx, rhj_copy_d2h(ctx, allh.data(), d_hall, allh.size()));
+                for (int r = 0; r < world; r++) {
+                    if (r == rank) continue;
+                    RHJOK(ctx, rhj_ipc_open(ctx, &allh[128 * (size_t)r], &pP[r]));
+                    RHJOK(ctx, rhj_ipc_open(ctx, &allh[128 * (size_t)r + 64], &pK[r]));
+                }
+            }
+            RHJOK(ctx, rhj_shard_split_peer(ctx, rel, (const rhj_tuple *)rel_in[rel], n, SHIFT, BITS, row0[rel][rank], owner, dst,
+                                            pP.data(), pK.data(), world));
+            trace("peer split enqueued");
+        }
+        // every sender's stores into my arrays must have completed before I read them: a one-word all-reduce behind the split
+        // kernels of all ranks on the shared stream
+        void *d_bar;
+        RHJOK(ctx, rhj_dev_alloc(ctx, 64, &d_bar));
+        NCCLOK(ncclAllReduce(d_bar, (char *)d_bar + 32, 1, ncclUint64, ncclSum, comm, st));
+    }
+    for (int rel = 0; rel < 2 && !peer_mode; rel++) {
         RHJOK(ctx, rhj_dev_alloc(ctx, rhj_narrow_bytes(n) + 16, &sendbuf[rel]));
         RHJOK(ctx, rhj_shard_split(ctx, rel, (const rhj_tuple *)rel_in[rel], n, SHIFT, BITS, row0[rel][rank], sendbuf[rel], nullptr));
         seg[rel][0] = 0;
@@ -224,7 +274,7 @@ int main(int argc, char **argv)
                "\"plan\": [%d, %d, %d], \"pairs_global\": %llu, \"ms_first_join\": %.2f, \"own_segment\": \"%s\", "
                "\"nccl_sends_rank0\": %llu, \"max_tuples_per_message\": %llu, \"verified\": %s}\n",
                world, (unsigned long long)n, zipf ? "zipf0.9" : "uniform", mode, plan.passes, plan.bits1, plan.bits2,
-               (unsigned long long)tot[0], ms, via_self ? "ncclSend/ncclRecv to self" : "device copy",
+               (unsigned long long)tot[0], ms, peer_mode ? "peer-mapped class split" : via_self ? "ncclSend/ncclRecv to self" : "device copy",
                (unsigned long long)messages, (unsigned long long)MAX_MSG, ok ? "true" : "false");
     rhj_destroy(ctx);
     NCCLOK(ncclCommDestroy(comm));

@@ -216,3 +216,105 @@ def test_split_of_another_relation_than_stats_saw_is_reported(engine):
         else:
             with pytest.raises(RhjError, match="did not fit 32 bits"):
                 engine.shard_join(None, 0)
+
+
+def peer_split_join(eng, shardsR, shardsS, plan, mode, check_against_send_buffers=True):
+    """the sharded schedule with rhj_shard_split_peer: every sender writes its classes straight into the owners' receive arrays
+    (here: buffers of the one GPU standing in for the peers' HBM) -- no send buffer, no all-to-all -- then the owners run the
+    receiver calls as usual.  Returns all pairs."""
+    world, C = len(shardsR), 1 << BITS
+    hists = {0: [], 1: []}
+    kmins = {0: [], 1: []}
+    for side, shards in ((0, shardsR), (1, shardsS)):
+        for t in shards:
+            d = eng.to_device(t)
+            h, kmin, _ = eng.shard_stats(side, d, len(t), SHIFT, BITS)
+            hists[side].append(h)
+            kmins[side].append(0 if mode == SHARD_PLAIN else kmin)
+            d.free()
+    total = np.sum(hists[0], axis=0) + np.sum(hists[1], axis=0)
+    cuts = balanced_cuts(total.tolist(), world)
+    owner = np.zeros(C, dtype=np.uint8)
+    for r in range(world):
+        owner[cuts[r]:cuts[r + 1]] = r
+    recvP, recvK, seg_off = {}, {}, {}
+    for side in (0, 1):
+        recvP[side], recvK[side], seg_off[side] = [], [], []
+        for r in range(world):
+            off = [0]
+            for s in range(world):
+                off.append(off[-1] + int(hists[side][s][cuts[r]:cuts[r + 1]].sum()))
+            seg_off[side].append(off)
+            recvP[side].append(eng.alloc(8 * max(off[-1], 1)))
+            recvK[side].append(eng.alloc(4 * max(off[-1], 1)))
+    for side, shards in ((0, shardsR), (1, shardsS)):
+        for s, t in enumerate(shards):
+            n = len(t)
+            d = eng.to_device(t)
+            eng.shard_stats(side, d, n, SHIFT, BITS)
+            dst = np.zeros(C, dtype=np.uint64)
+            for r in range(world):
+                at = seg_off[side][r][s]
+                for c in range(cuts[r], cuts[r + 1]):
+                    dst[c] = at
+                    at += int(hists[side][s][c])
+            eng.shard_split_peer(side, d, n, SHIFT, BITS, kmins[side][s], owner, dst, recvP[side], recvK[side])
+            eng.sync()
+            if check_against_send_buffers:                   # the same tuples, at the same places, as send buffer + slicing delivers
+                buf = eng.alloc(max(narrow_bytes(n), 16))
+                eng.shard_split(side, d, n, SHIFT, BITS, kmins[side][s], buf)
+                raw = buf.to_numpy(np.uint8, narrow_bytes(n))
+                P = raw[:8 * n].view(np.uint64)
+                K = raw[narrow_key_offset(n):narrow_key_offset(n) + 4 * n].view(np.uint32)
+                st = np.concatenate([[0], np.cumsum(hists[side][s])]).astype(np.int64)
+                for r in range(world):
+                    a, b = int(st[cuts[r]]), int(st[cuts[r + 1]])
+                    lo = seg_off[side][r][s]
+                    m = seg_off[side][r][-1]
+                    gotP = recvP[side][r].to_numpy(np.uint64, max(m, 1))[lo:lo + b - a]
+                    gotK = recvK[side][r].to_numpy(np.uint32, max(m, 1))[lo:lo + b - a]
+                    assert np.array_equal(gotP, P[a:b]) and np.array_equal(gotK, K[a:b])
+                buf.free()
+            d.free()
+    pairs = []
+    for r in range(world):
+        for side in (0, 1):
+            m = seg_off[side][r][-1]
+            eng.shard_partition(side, recvP[side][r], recvK[side][r], m, seg_off[side][r], kmins[side], plan, mode)
+            eng.sync()
+        cnt = eng.shard_join(None, 0)
+        out = eng.alloc(16 * max(cnt, 1))
+        assert eng.shard_join(out, cnt) == cnt
+        pairs.append(out.to_numpy(np.uint64, 2 * cnt).reshape(-1, 2))
+        out.free()
+    for side in (0, 1):
+        for b in recvP[side] + recvK[side]:
+            b.free()
+    return np.concatenate(pairs)
+
+
+@pytest.mark.parametrize("world,n_per,nlow,dup,plan,kernel,mode", [
+    (3, 60_000, 0, 1, Opts(2, 4, 4), BKT, SHARD_TAGGED),
+    (8, 20_000, 4, 1, Opts(2, 8, 8), CT, SHARD_GLOBAL16),
+    (4, 30_000, 5, 2, Opts(2, 8, 8), CT, SHARD_PLAIN),
+    (2, 300_000, 0, 1, Opts(2, 6, 6), BKT, SHARD_PLAIN),          # several tiles per unit and several units per sender
+])
+def test_peer_mapped_class_split_equals_global_join(oracle, world, n_per, nlow, dup, plan, kernel, mode):
+    """rhj_shard_split_peer (DESIGN §9 of round 3, built): sender kernels store into the owners' arrays through a table of
+    per-destination base pointers; identical bytes to send buffer + all-to-all, and the global join's pair set"""
+    rng = np.random.default_rng(world * 77 + n_per)
+    Rs, Ss = global_relations(rng, world, n_per, nlow, dup, stride=(1 << 30) // 4 if mode == SHARD_PLAIN else (5 << 30))
+    _, rplan = shard_plan(n_per, n_per, plan)
+    eng = Engine(0)
+    try:
+        if kernel != BKT:
+            eng.set_option("join.big_tables", 1)
+            eng.set_option("join.big_kernel", kernel)
+        got = peer_split_join(eng, Rs, Ss, rplan, mode)
+    finally:
+        eng.close()
+    exp = oracle.join(np.concatenate(Rs), np.concatenate(Ss))
+    assert len(got) == len(exp)
+    a = got[np.lexsort((got[:, 1], got[:, 0]))]
+    e = np.stack([exp["keyR"], exp["keyS"]], axis=1)
+    assert np.array_equal(a, e[np.lexsort((e[:, 1], e[:, 0]))])

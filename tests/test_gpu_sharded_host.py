@@ -47,3 +47,18 @@ def test_cpp_host_send_recv_loop_in_pieces_to_self(tmp_path, rows, dist_, max_ms
     assert line["own_segment"] == "ncclSend/ncclRecv to self" and line["max_tuples_per_message"] == max_msg
     pieces = -(-rows // max_msg)
     assert line["nccl_sends_rank0"] == 2 * 2 * pieces             # payloads + rowIDs, R and S
+
+
+def test_cpp_host_peer_mapped_split(tmp_path):
+    """RHJ_SHARD_PEER=1: the class split of sharded_host.cpp stores straight into the owner's receive arrays
+    (rhj_shard_split_peer): no send buffer, no ncclSend / ncclRecv.  One rank: the owner is the rank itself (the hipIpc leg of
+    a multi-rank run cannot execute on a one-GPU box)."""
+    if not os.path.exists(BIN):
+        pytest.skip("sharded_host not built")
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", RHJ_SHARD_PEER="1")
+    for rows, dist_ in ((12_000_000, "uniform"), (20_000_000, "zipf")):
+        r = subprocess.run([BIN, "0", "1", str(tmp_path / "nccl_id"), str(rows), dist_], capture_output=True, text=True, timeout=600, env=env)
+        assert r.returncode == 0, (r.stdout[-1000:], r.stderr[-2000:])
+        line = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+        assert line["verified"] is True and line["pairs_global"] == rows
+        assert line["own_segment"] == "peer-mapped class split" and line["nccl_sends_rank0"] == 0

@@ -273,7 +273,13 @@ def peer_split_join(eng, shardsR, shardsS, plan, mode, check_against_send_buffer
                     m = seg_off[side][r][-1]
                     gotP = recvP[side][r].to_numpy(np.uint64, max(m, 1))[lo:lo + b - a]
                     gotK = recvK[side][r].to_numpy(np.uint32, max(m, 1))[lo:lo + b - a]
-                    assert np.array_equal(gotP, P[a:b]) and np.array_equal(gotK, K[a:b])
+                    # class by class the same {payload, rowID} tuples (the order INSIDE a class is the order in which a tile's
+                    # lanes won their LDS atomics: unspecified, and different from launch to launch)
+                    for c in range(cuts[r], cuts[r + 1]):
+                        x, y = int(st[c]) - a, int(st[c + 1]) - a
+                        g = np.stack([gotP[x:y], gotK[x:y].astype(np.uint64)], axis=1)
+                        w = np.stack([P[a + x:a + y], K[a + x:a + y].astype(np.uint64)], axis=1)
+                        assert np.array_equal(g[np.lexsort((g[:, 1], g[:, 0]))], w[np.lexsort((w[:, 1], w[:, 0]))]), (side, s, r, c)
                 buf.free()
             d.free()
     pairs = []
@@ -301,7 +307,8 @@ def peer_split_join(eng, shardsR, shardsS, plan, mode, check_against_send_buffer
 ])
 def test_peer_mapped_class_split_equals_global_join(oracle, world, n_per, nlow, dup, plan, kernel, mode):
     """rhj_shard_split_peer (DESIGN §9 of round 3, built): sender kernels store into the owners' arrays through a table of
-    per-destination base pointers; identical bytes to send buffer + all-to-all, and the global join's pair set"""
+    per-destination base pointers; class by class the same tuples as send buffer + all-to-all delivers, and the global join's
+    pair set"""
     rng = np.random.default_rng(world * 77 + n_per)
     Rs, Ss = global_relations(rng, world, n_per, nlow, dup, stride=(1 << 30) // 4 if mode == SHARD_PLAIN else (5 << 30))
     _, rplan = shard_plan(n_per, n_per, plan)

@@ -242,6 +242,90 @@ def shard_rank_kernel_time(eng, torch, dev, world, n, dist_kind):
                     "kernels; the exchange itself is modelled (direct peer links, all busy)"}
 
 
+def extras_host(eng, which="all"):
+    """N == 1 only, outside the timed region and BEFORE the headline's buffers exist: the host-pointer legs (the drop-in call end
+    to end, the 94 joins of small.work single / batched / from 8 threads).  They run first because a process that has just
+    released a few hundred GB of HBM sees its device-to-host copies run at half rate for a while ([measured] round 3: 126 ms
+    instead of 87-94 for the 128M leg when it ran after the 10^9-tuple legs) -- a property of the runtime, not of the join."""
+    import numpy as np
+    import radixhashjoin_amd as rhj
+    res = {}
+    # the drop-in as the reference calls it: host AoS in, one malloc'd result page out (PCIe inclusive, pageable memory)
+    n = 128_000_000 if which == "all" else 16_000_000
+    Rh, Sh = host_inputs(n, rhj.TUPLE)
+    eng.join(Rh[:1_000_000], Sh[:1_000_000])
+    secs = []
+    for _ in range(3):
+        cnt, dt_call = eng.join_count_only_page(Rh, Sh, timed=True)          # the C call alone (the page is freed outside)
+        secs.append(dt_call)
+    sec = sorted(secs)[1]
+    res[f"end_to_end_rhj_join_{n // 1_000_000}Mx{n // 1_000_000}M"] = {"ms": sec * 1e3, "tuples_per_s": 2 * n / sec, "matches": cnt,
+                                            "pcie_GBps": (32.0 * n + 16.0 * cnt) / sec / 1e9, "runs_ms": [round(x * 1e3, 1) for x in secs],
+                                            "s_chunks_pipelined": eng.info("last.pipelined"),
+                                            "note": "H2D of both inputs from pageable memory + kernels + D2H of the result page; pcie_GBps = (input + "
+                                                    "result bytes) / wall time, above one direction's wire rate when download overlaps upload"}
+    del Rh, Sh
+
+    # config 1's joins: the 94 multiRadixHashJoin calls the reference makes on small.work (sizes from the link-time tap,
+    # tests/golden/small_joins.json), synthetic inputs of those sizes and match counts, through the host-pointer call
+    meta = json.load(open(os.path.join(ROOT, "tests", "golden", "small_joins.json")))["calls"]
+    rng = np.random.default_rng(1)
+    cases = []
+    for c in meta:
+        nR, nS, m = c["nR"], c["nS"], max(c["count"], 1)
+        D = max(1, int(nR * nS / m))
+        Rt = np.empty(nR, dtype=rhj.TUPLE); Rt["key"] = np.arange(nR); Rt["payload"] = rng.integers(0, D, nR, dtype=np.uint64)
+        St = np.empty(nS, dtype=rhj.TUPLE); St["key"] = np.arange(nS); St["payload"] = rng.integers(0, D, nS, dtype=np.uint64)
+        cases.append((Rt, St))
+    for Rt, St in cases:
+        eng.join_count_only_page(Rt, St)
+    t0 = time.perf_counter()
+    reps = 5
+    for _ in range(reps):
+        for Rt, St in cases:
+            eng.join_count_only_page(Rt, St)
+    sec = (time.perf_counter() - t0) / reps
+    res["small_work_94_joins_rhj_join"] = {"total_ms": sec * 1e3, "mean_us_per_join": sec / len(cases) * 1e6,
+                                           "tuples_per_s": sum(len(a) + len(b) for a, b in cases) / sec}
+    # ... and through rhj_join_batch from the same ONE thread: sixteen joins per launch, one staged upload and one
+    # synchronisation per sixteen (the kernel writes the pairs into pinned host memory itself)
+    eng.join_batch(cases, keep_pairs=False)
+    secs_b = []
+    for _ in range(reps):
+        cnts, dt_b = eng.join_batch(cases, keep_pairs=False, timed=True)
+        secs_b.append(dt_b)
+    sec_b = sorted(secs_b)[len(secs_b) // 2]
+    single_counts = [eng.join_count_only_page(Rt, St) for Rt, St in cases]
+    res["small_work_94_joins_rhj_join_batch"] = {"total_ms": sec_b * 1e3, "mean_us_per_join": sec_b / len(cases) * 1e6,
+                                                 "tuples_per_s": sum(len(a) + len(b) for a, b in cases) / sec_b,
+                                                 "same_counts_as_rhj_join": [int(c) for c in cnts] == [int(c) for c in single_counts],
+                                                 "note": "ONE caller thread, the C call alone (pages freed outside), median of %d" % reps}
+    # the same 94 joins the way the reference issues them: 8 query threads (join.cpp:42-43, MainScheduler.cpp:6-14), each
+    # with its own scheduler = its own rhj_ctx and HIP stream; ctypes releases the GIL inside the C call
+    import threading
+    nthr = 8
+    engines = [rhj.Engine(0) for _ in range(nthr)]
+    for k, e2 in enumerate(engines):
+        for Rt, St in cases[k::nthr]:
+            e2.join_count_only_page(Rt, St)
+    def work(k, reps_):
+        for _ in range(reps_):
+            for Rt, St in cases[k::nthr]:
+                engines[k].join_count_only_page(Rt, St)
+    t0 = time.perf_counter()
+    thr = [threading.Thread(target=work, args=(k, reps)) for k in range(nthr)]
+    for t in thr:
+        t.start()
+    for t in thr:
+        t.join()
+    sec8 = (time.perf_counter() - t0) / reps
+    for e2 in engines:
+        e2.close()
+    res["small_work_94_joins_rhj_join_8_query_threads"] = {"total_ms": sec8 * 1e3, "mean_us_per_join": sec8 / len(cases) * 1e6,
+                                                           "note": "wall time of the 94 calls spread over 8 host threads, one context each"}
+    return res
+
+
 def extras(eng, torch, dev, steps, which="all"):
     """N == 1 only, outside the timed region: the other BASELINE configs and the host-pointer drop-in, so that every
     number DESIGN.md quotes is on the driver's record.  Each leg verifies its pair set (count + checksum)."""
@@ -258,22 +342,6 @@ def extras(eng, torch, dev, steps, which="all"):
             cnt = eng.join_dev(R, n, S, n, out, out.shape[0], opts=opts)
         torch.cuda.synchronize()
         return cnt, (time.perf_counter() - t0) / reps
-
-    # the drop-in as the reference calls it: host AoS in, one malloc'd result page out (PCIe inclusive, pageable memory)
-    n = 128_000_000 if which == "all" else 16_000_000
-    Rh, Sh = host_inputs(n, rhj.TUPLE)
-    eng.join(Rh[:1_000_000], Sh[:1_000_000])
-    secs = []
-    for _ in range(3):
-        cnt, dt_call = eng.join_count_only_page(Rh, Sh, timed=True)          # the C call alone (the page is freed outside)
-        secs.append(dt_call)
-    sec = sorted(secs)[1]
-    res[f"end_to_end_rhj_join_{n // 1_000_000}Mx{n // 1_000_000}M"] = {"ms": sec * 1e3, "tuples_per_s": 2 * n / sec, "matches": cnt,
-                                            "pcie_GBps": (32.0 * n + 16.0 * cnt) / sec / 1e9, "runs_ms": [round(x * 1e3, 1) for x in secs],
-                                            "s_chunks_pipelined": eng.info("last.pipelined"),
-                                            "note": "H2D of both inputs from pageable memory + kernels + D2H of the result page; pcie_GBps = (input + "
-                                                    "result bytes) / wall time, above one direction's wire rate when download overlaps upload"}
-    del Rh, Sh
 
     # config 2: 1M x 1M uniform, one 8-bit pass (what the automatic plan picks), device-resident
     n = 1_000_000
@@ -363,63 +431,6 @@ def extras(eng, torch, dev, steps, which="all"):
         eng.release_workspace()
         torch.cuda.empty_cache()
 
-    # config 1's joins: the 94 multiRadixHashJoin calls the reference makes on small.work (sizes from the link-time tap,
-    # tests/golden/small_joins.json), synthetic inputs of those sizes and match counts, through the host-pointer call
-    meta = json.load(open(os.path.join(ROOT, "tests", "golden", "small_joins.json")))["calls"]
-    rng = np.random.default_rng(1)
-    cases = []
-    for c in meta:
-        nR, nS, m = c["nR"], c["nS"], max(c["count"], 1)
-        D = max(1, int(nR * nS / m))
-        Rt = np.empty(nR, dtype=rhj.TUPLE); Rt["key"] = np.arange(nR); Rt["payload"] = rng.integers(0, D, nR, dtype=np.uint64)
-        St = np.empty(nS, dtype=rhj.TUPLE); St["key"] = np.arange(nS); St["payload"] = rng.integers(0, D, nS, dtype=np.uint64)
-        cases.append((Rt, St))
-    for Rt, St in cases:
-        eng.join_count_only_page(Rt, St)
-    t0 = time.perf_counter()
-    reps = 5
-    for _ in range(reps):
-        for Rt, St in cases:
-            eng.join_count_only_page(Rt, St)
-    sec = (time.perf_counter() - t0) / reps
-    res["small_work_94_joins_rhj_join"] = {"total_ms": sec * 1e3, "mean_us_per_join": sec / len(cases) * 1e6,
-                                           "tuples_per_s": sum(len(a) + len(b) for a, b in cases) / sec}
-    # ... and through rhj_join_batch from the same ONE thread: sixteen joins per launch, one staged upload and one
-    # synchronisation per sixteen (the kernel writes the pairs into pinned host memory itself)
-    eng.join_batch(cases, keep_pairs=False)
-    secs_b = []
-    for _ in range(reps):
-        cnts, dt_b = eng.join_batch(cases, keep_pairs=False, timed=True)
-        secs_b.append(dt_b)
-    sec_b = sorted(secs_b)[len(secs_b) // 2]
-    single_counts = [eng.join_count_only_page(Rt, St) for Rt, St in cases]
-    res["small_work_94_joins_rhj_join_batch"] = {"total_ms": sec_b * 1e3, "mean_us_per_join": sec_b / len(cases) * 1e6,
-                                                 "tuples_per_s": sum(len(a) + len(b) for a, b in cases) / sec_b,
-                                                 "same_counts_as_rhj_join": [int(c) for c in cnts] == [int(c) for c in single_counts],
-                                                 "note": "ONE caller thread, the C call alone (pages freed outside), median of %d" % reps}
-    # the same 94 joins the way the reference issues them: 8 query threads (join.cpp:42-43, MainScheduler.cpp:6-14), each
-    # with its own scheduler = its own rhj_ctx and HIP stream; ctypes releases the GIL inside the C call
-    import threading
-    nthr = 8
-    engines = [rhj.Engine(0) for _ in range(nthr)]
-    for k, e2 in enumerate(engines):
-        for Rt, St in cases[k::nthr]:
-            e2.join_count_only_page(Rt, St)
-    def work(k, reps_):
-        for _ in range(reps_):
-            for Rt, St in cases[k::nthr]:
-                engines[k].join_count_only_page(Rt, St)
-    t0 = time.perf_counter()
-    thr = [threading.Thread(target=work, args=(k, reps)) for k in range(nthr)]
-    for t in thr:
-        t.start()
-    for t in thr:
-        t.join()
-    sec8 = (time.perf_counter() - t0) / reps
-    for e2 in engines:
-        e2.close()
-    res["small_work_94_joins_rhj_join_8_query_threads"] = {"total_ms": sec8 * 1e3, "mean_us_per_join": sec8 / len(cases) * 1e6,
-                                                           "note": "wall time of the 94 calls spread over 8 host threads, one context each"}
     return res
 
 
@@ -476,6 +487,7 @@ def main():
     n = args.tuples
     nglobal = n * world
     opts = rhj.Opts(2, args.bits1, args.bits2) if args.passes == 2 else rhj.Opts(1, args.bits1, 0)
+    early = extras_host(eng, args.extras) if world == 1 and not args.no_extras else {}
 
     # inputs resident in HBM, generated on device (SURVEY §8d generators; 16 B AoS tuples)
     R = torch.empty((n, 2), dtype=torch.int64, device=dev)
@@ -675,7 +687,7 @@ def main():
             R = S = out = res = None                      # the headline inputs are done with: HBM back for the other configs
             eng.release_workspace()
             torch.cuda.empty_cache()
-            line["other_configs"] = extras(eng, torch, dev, args.steps, args.extras)
+            line["other_configs"] = dict(early, **extras(eng, torch, dev, args.steps, args.extras))
         if world == 1 and args.cpu_sample > 0:
             line["cpu_baseline"] = cpu_baseline(args.cpu_sample)
             line["gpu_over_cpu"] = value / line["cpu_baseline"]["value"]

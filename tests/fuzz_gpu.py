@@ -41,13 +41,23 @@ def rel(n, dom, skew, key0):
     else:                # one hot value + uniform rest
         v = rng.integers(0, dom, n, dtype=np.uint64)
         v[rng.random(n) < 0.5] = np.uint64(dom // 2)
-    mode = rng.integers(0, 3)
-    if mode == 1:
-        v = v * np.uint64(0x9E3779B97F4A7C15)            # spread the values over all 64 bits (bijective)
-    elif mode == 2:
-        v = v << np.uint64(rng.integers(0, 40))
     t["payload"] = v
     return t
+
+
+def shape(R, S):
+    """the same re-labelling of the join values on both sides: spread over 64 bits, aligned (multiples of 2^k: what raw-bit radix
+    digits choke on), or values whose MIXED form shares its low 16 bits (few, large partitions after rhj_mix64)"""
+    mode = int(rng.integers(0, 4))
+    for t in (R, S):
+        v = t["payload"]
+        if mode == 1:
+            v = v * np.uint64(0x9E3779B97F4A7C15)
+        elif mode == 2:
+            v = v << np.uint64(shape.k)
+        elif mode == 3:
+            v = rhj.unmix64((v << np.uint64(16)) | np.uint64(0xBEEF))
+        t["payload"] = v
 
 
 t0, cases, maxout, narrow_runs, fallbacks = time.time(), 0, 0, 0, 0
@@ -56,6 +66,10 @@ while time.time() - t0 < budget:
     dom = int(rng.choice([1, 2, 5, 100, 4096, 70_000, 1 << 22, 1 << 40]))
     skR, skS = int(rng.integers(0, 3)), int(rng.integers(0, 3))
     R, S = rel(nR, dom, skR, 0), rel(nS, dom, skS, 10**7)
+    shape.k = int(rng.integers(0, 40))
+    shape(R, S)
+    e.set_option("partition.mix", int(rng.random() < 0.85))                 # mostly the default; raw digits now and then
+    e.set_option("join.fused", int(rng.random() < 0.8))
     # expected output size first (value counts), so that neither the oracle nor the GPU materialises a huge result
     vr, cr = np.unique(R["payload"], return_counts=True)
     vs, cs = np.unique(S["payload"], return_counts=True)

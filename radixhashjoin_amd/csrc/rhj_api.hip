@@ -173,6 +173,9 @@ struct rhj_ctx {
     DevBuf ps_R, ps_S, ps_1;           // partition boundaries (final R, final S, pass-1 scratch)
     DevBuf seg0, unit_start, unit_hist, unit_base;
     DevBuf seg0_b, unit_start_b, unit_hist_b, unit_base_b, scan_tmp_b;   // second relation of a paired pass
+    DevBuf hist2_b, grp_rng_b, unit_start2_b, ps_1_b, part_tmp_b;        // ... and of a two-pass join partitioned on two streams
+    hipStream_t aux_stream = nullptr;  // S of a mid-size two-pass join is partitioned here while R runs on `stream`
+    hipEvent_t aux_ev[2] = {nullptr, nullptr};
     DevBuf tasks, counters;            // counters: [0] u64 out_count, [1] u32 ntasks (+pad), [2] u64 checksum
     DevBuf out_pairs;                  // rhj_join's device result buffer
     DevBuf small_out;                  // small-join path: 64-byte header {count} + pairs, fetched in one D2H
@@ -607,6 +610,22 @@ int run_pass_pair(rhj_ctx *ctx, const void *d_R, u64 nR, void *outR, u64 *psR, c
 // Input: 16-byte tuples (in.aos), or -- the multi-GPU receiver -- narrow arrays that arrived in nseg sender segments
 // (in.P / in.K / in.seg_off; narrow is then 2): pass-1 units are cut at the segment boundaries and pass 2 writes the sender
 // number into the low payload bits (k_scatter_wcn's WnTag), which the join kernels resolve into global rowIDs.
+// the scratch tables one relation's fused two-pass partition works in, and the stream it runs on
+struct PartScratch {
+    DevBuf *seg0, *unit_start, *unit_hist, *unit_base, *scan_tmp, *hist2, *grp_rng, *unit_start2, *ps_1, *part_tmp, *seg_rng;
+    hipStream_t st;
+};
+PartScratch first_scratch(rhj_ctx *ctx)
+{
+    return PartScratch{&ctx->seg0, &ctx->unit_start, &ctx->unit_hist, &ctx->unit_base, &ctx->scan_tmp, &ctx->hist2, &ctx->grp_rng,
+                       &ctx->unit_start2, &ctx->ps_1, &ctx->part_tmp, &ctx->seg_rng, ctx->stream};
+}
+PartScratch second_scratch(rhj_ctx *ctx)
+{
+    return PartScratch{&ctx->seg0_b, &ctx->unit_start_b, &ctx->unit_hist_b, &ctx->unit_base_b, &ctx->scan_tmp_b, &ctx->hist2_b, &ctx->grp_rng_b,
+                       &ctx->unit_start2_b, &ctx->ps_1_b, &ctx->part_tmp_b, &ctx->seg_rng, ctx->aux_stream};
+}
+
 struct FusedIn {
     const void *aos = nullptr;
     const u64 *P = nullptr;
@@ -622,8 +641,15 @@ struct FusedIn {
 // mix (16-byte input only): MIX_STORE inside a join -- the histogram and pass 1 take their digits from mix64(payload) and pass 1
 // writes the mixed value, so that pass 2 and the bucket join work on it unchanged
 int partition_relation_fused(rhj_ctx *ctx, const FusedIn &in, u64 n, int b1, int b2, void *d_out, u64 *d_ps, int narrow = 0,
-                             int mix = MIX_NONE)
+                             int mix = MIX_NONE, const PartScratch *scratch = nullptr)
 {
+    // the scratch tables and the stream of this relation: the context's first set on its stream, or -- R and S of a mid-size
+    // join partitioned side by side -- the second set on the auxiliary stream (partition_phase)
+    const PartScratch sc = scratch ? *scratch : first_scratch(ctx);
+    DevBuf &x_seg0 = *sc.seg0, &x_unit_start = *sc.unit_start, &x_unit_hist = *sc.unit_hist, &x_unit_base = *sc.unit_base,
+           &x_scan_tmp = *sc.scan_tmp, &x_hist2 = *sc.hist2, &x_grp_rng = *sc.grp_rng, &x_unit_start2 = *sc.unit_start2,
+           &x_ps_1 = *sc.ps_1, &x_part_tmp = *sc.part_tmp, &x_seg_rng = *sc.seg_rng;
+    const hipStream_t st = sc.st;
     const bool segs = in.P != nullptr;
     // 1024 pass-1 units instead of 2048: every unit flushes a 2^(b1+b2)-bin table, and the scatter does not care
     // ([measured] at 10^9 tuples: histogram 2.54 against 2.74 ms, scatter within noise)
@@ -654,84 +680,84 @@ int partition_relation_fused(rhj_ctx *ctx, const FusedIn &in, u64 n, int b1, int
     }
     const size_t nb1 = (size_t)1 << b1, nb2 = (size_t)1 << b2;
     const u32 units2 = (u32)(nb1 * ngroups);
-    RHJCHK(ensure(ctx, ctx->seg0, 64));
-    RHJCHK(ensure(ctx, ctx->unit_start, 16));
-    RHJCHK(ensure(ctx, ctx->unit_hist, (size_t)(units1 + 1) * nb1 * 4));
-    RHJCHK(ensure(ctx, ctx->unit_base, (size_t)((units1 + 1) * nb1 > units2 * nb2 ? (units1 + 1) * nb1 : units2 * nb2) * 8));
-    RHJCHK(ensure(ctx, ctx->scan_tmp, scan_tmp_bytes(b1)));
-    RHJCHK(ensure(ctx, ctx->hist2, (size_t)units2 * nb2 * 4));
-    RHJCHK(ensure(ctx, ctx->grp_rng, ((size_t)units2 + 1) * 8));
-    RHJCHK(ensure(ctx, ctx->unit_start2, (nb1 + 1) * 4));
-    RHJCHK(ensure(ctx, ctx->part_tmp, (size_t)(n ? n : 1) * 16));
-    RHJCHK(ensure(ctx, ctx->ps_1, (nb1 + 1) * 8));
-    if (segs) RHJCHK(ensure(ctx, ctx->seg_rng, ((size_t)units1 + 1) * 8));
-    u64 *seg0 = (u64 *)ctx->seg0.p;
-    u32 *unit_start1 = (u32 *)ctx->unit_start.p;
-    const u64 *rng1 = segs ? (const u64 *)ctx->seg_rng.p : nullptr;
+    RHJCHK(ensure(ctx, x_seg0, 64));
+    RHJCHK(ensure(ctx, x_unit_start, 16));
+    RHJCHK(ensure(ctx, x_unit_hist, (size_t)(units1 + 1) * nb1 * 4));
+    RHJCHK(ensure(ctx, x_unit_base, (size_t)((units1 + 1) * nb1 > units2 * nb2 ? (units1 + 1) * nb1 : units2 * nb2) * 8));
+    RHJCHK(ensure(ctx, x_scan_tmp, scan_tmp_bytes(b1)));
+    RHJCHK(ensure(ctx, x_hist2, (size_t)units2 * nb2 * 4));
+    RHJCHK(ensure(ctx, x_grp_rng, ((size_t)units2 + 1) * 8));
+    RHJCHK(ensure(ctx, x_unit_start2, (nb1 + 1) * 4));
+    RHJCHK(ensure(ctx, x_part_tmp, (size_t)(n ? n : 1) * 16));
+    RHJCHK(ensure(ctx, x_ps_1, (nb1 + 1) * 8));
+    if (segs) RHJCHK(ensure(ctx, x_seg_rng, ((size_t)units1 + 1) * 8));
+    u64 *seg0 = (u64 *)x_seg0.p;
+    u32 *unit_start1 = (u32 *)x_unit_start.p;
+    const u64 *rng1 = segs ? (const u64 *)x_seg_rng.p : nullptr;
     u32 *wide = narrow ? (u32 *)ctx->narrow_flag.p : nullptr;
     PassGeom gs = g1;                                   // (segmented: the scan only needs the unit count)
     gs.max_units = units1;
     {
         Span s(ctx, RHJ_K_AUX);
-        if (segs) launch_seg_units(ctx->stream, (u32)in.nseg, in.seg_off, segL, groups_per_seg * per, (u64 *)ctx->seg_rng.p, seg0, unit_start1);
-        else launch_init_single_segment(ctx->stream, n, g1.L, seg0, unit_start1);          // seg0 = {0,n}, unit_start1 = {0, units1}
-        HIPCHK(ctx, hipMemsetAsync(ctx->hist2.p, 0, (size_t)units2 * nb2 * 4, ctx->stream));
+        if (segs) launch_seg_units(st, (u32)in.nseg, in.seg_off, segL, groups_per_seg * per, (u64 *)x_seg_rng.p, seg0, unit_start1);
+        else launch_init_single_segment(st, n, g1.L, seg0, unit_start1);          // seg0 = {0,n}, unit_start1 = {0, units1}
+        HIPCHK(ctx, hipMemsetAsync(x_hist2.p, 0, (size_t)units2 * nb2 * 4, st));
     }
     {
         Span s(ctx, RHJ_K_HIST);                        // (16-byte input: also reports a rowID that does not fit the narrow format)
-        launch_hist2d_units(ctx->stream, segs ? (const void *)in.P : in.aos, segs, n, g1.L, units1, b1, b2, per, ngroups,
-                            (u32 *)ctx->unit_hist.p, (u32 *)ctx->hist2.p, 0, wide, rng1, g1.mix);
+        launch_hist2d_units(st, segs ? (const void *)in.P : in.aos, segs, n, g1.L, units1, b1, b2, per, ngroups,
+                            (u32 *)x_unit_hist.p, (u32 *)x_hist2.p, 0, wide, rng1, g1.mix);
     }
     {
         Span s(ctx, RHJ_K_SCAN);
-        launch_scan_units(ctx->stream, gs, seg0, unit_start1, (const u32 *)ctx->unit_hist.p, (u64 *)ctx->unit_base.p,
-                          (u64 *)ctx->ps_1.p, (u64 *)ctx->scan_tmp.p);
+        launch_scan_units(st, gs, seg0, unit_start1, (const u32 *)x_unit_hist.p, (u64 *)x_unit_base.p,
+                          (u64 *)x_ps_1.p, (u64 *)x_scan_tmp.p);
     }
     {
         Span s(ctx, RHJ_K_SCATTER);
         if (segs)
-            launch_scatter_ranges_narrow(ctx->stream, in.P, true, ctx->part_tmp.p, n, units1, 0, b1, (const u64 *)ctx->unit_base.p,
+            launch_scatter_ranges_narrow(st, in.P, true, x_part_tmp.p, n, units1, 0, b1, (const u64 *)x_unit_base.p,
                                          rng1, wide, 0, 0, in.K);
         else if (narrow == 2)
-            launch_scatter_units_narrow(ctx->stream, in.aos, ctx->part_tmp.p, n, g1, seg0, unit_start1, (const u64 *)ctx->unit_base.p,
+            launch_scatter_units_narrow(st, in.aos, x_part_tmp.p, n, g1, seg0, unit_start1, (const u64 *)x_unit_base.p,
                                         wide);
         else
-            launch_scatter_units(ctx->stream, in.aos, ctx->part_tmp.p, g1, seg0, unit_start1, (const u64 *)ctx->unit_base.p);
+            launch_scatter_units(st, in.aos, x_part_tmp.p, g1, seg0, unit_start1, (const u64 *)x_unit_base.p);
     }
     {
         Span s(ctx, RHJ_K_AUX);
-        launch_make_group_ranges(ctx->stream, (const u64 *)ctx->unit_base.p, (u32)nb1, per, ngroups, n, (u64 *)ctx->grp_rng.p,
-                                 (u32 *)ctx->unit_start2.p);
+        launch_make_group_ranges(st, (const u64 *)x_unit_base.p, (u32)nb1, per, ngroups, n, (u64 *)x_grp_rng.p,
+                                 (u32 *)x_unit_start2.p);
     }
     PassGeom g2;
     g2.n = n; g2.L = 0; g2.nseg = (u32)nb1; g2.max_units = units2; g2.shift = b1; g2.bits = b2;
     {
         Span s(ctx, RHJ_K_SCAN);
-        launch_scan_units(ctx->stream, g2, (const u64 *)ctx->ps_1.p, (const u32 *)ctx->unit_start2.p, (const u32 *)ctx->hist2.p,
-                          (u64 *)ctx->unit_base.p, d_ps, nullptr);
+        launch_scan_units(st, g2, (const u64 *)x_ps_1.p, (const u32 *)x_unit_start2.p, (const u32 *)x_hist2.p,
+                          (u64 *)x_unit_base.p, d_ps, nullptr);
     }
     {
         Span s(ctx, RHJ_K_SCATTER);
         if (segs && in.final_form == 2)
-            launch_scatter_ranges_n2a(ctx->stream, ctx->part_tmp.p, d_out, n, units2, b1, b2, (const u64 *)ctx->unit_base.p,
-                                      (const u64 *)ctx->grp_rng.p, in.key_bases, ngroups, groups_per_seg, wide);
+            launch_scatter_ranges_n2a(st, x_part_tmp.p, d_out, n, units2, b1, b2, (const u64 *)x_unit_base.p,
+                                      (const u64 *)x_grp_rng.p, in.key_bases, ngroups, groups_per_seg, wide);
         else if (narrow)
-            launch_scatter_ranges_narrow(ctx->stream, ctx->part_tmp.p, narrow == 2, d_out, n, units2, b1, b2,
-                                         (const u64 *)ctx->unit_base.p, (const u64 *)ctx->grp_rng.p, wide,
+            launch_scatter_ranges_narrow(st, x_part_tmp.p, narrow == 2, d_out, n, units2, b1, b2,
+                                         (const u64 *)x_unit_base.p, (const u64 *)x_grp_rng.p, wide,
                                          segs && in.final_form == 1 ? ngroups : 0u, segs && in.final_form == 1 ? groups_per_seg : 0u);
         else
-            launch_scatter_ranges(ctx->stream, ctx->part_tmp.p, d_out, units2, b1, b2, (const u64 *)ctx->unit_base.p,
-                                  (const u64 *)ctx->grp_rng.p);
+            launch_scatter_ranges(st, x_part_tmp.p, d_out, units2, b1, b2, (const u64 *)x_unit_base.p,
+                                  (const u64 *)x_grp_rng.p);
     }
     return check_launch(ctx, "fused two-pass partition");
 }
 
 int partition_relation_fused(rhj_ctx *ctx, const void *d_in, u64 n, int b1, int b2, void *d_out, u64 *d_ps, int narrow = 0,
-                             int mix = MIX_NONE)
+                             int mix = MIX_NONE, const PartScratch *scratch = nullptr)
 {
     FusedIn in;
     in.aos = d_in;
-    return partition_relation_fused(ctx, in, n, b1, b2, d_out, d_ps, narrow, mix);
+    return partition_relation_fused(ctx, in, n, b1, b2, d_out, d_ps, narrow, mix, scratch);
 }
 
 // Two narrow passes with SEPARATE histograms (plans of 17-18 bits: 2^(b1+b2) packed counters do not fit the LDS, so the
@@ -868,6 +894,19 @@ bool is_direct(const rhj_ctx *ctx, u64 nparts, u64 nR, u64 nS)
            (nR < nS ? nS : nR) <= DIRECT_MAX_PROBE;
 }
 
+// R and S of a fused two-pass plan side by side on two streams: device-resident joins (nothing to upload in between) of at
+// most 2^28 tuples per side (the second pass-1 intermediate costs 16 B per tuple of S), not while profiling (spans are timed
+// on one stream).  RHJ_TWO_STREAMS=0 switches it off.
+bool two_streams_ok(const rhj_ctx *ctx, u64 nR, u64 nS, const rhj_opts &plan, std::function<int()> *before_S)
+{
+    static const bool on = env_u64("RHJ_TWO_STREAMS", 1, 0, 1) != 0;
+    if (!on || ctx->prof.on || (before_S && *before_S)) return false;
+    if (plan.passes != 2 || !fused_two_pass_ok(plan.bits1, plan.bits2)) return false;
+    if (ctx->cur_narrow && !narrow_fused_plan(plan)) return false;
+    const u64 hi = nR > nS ? nR : nS, lo = nR > nS ? nS : nR;
+    return lo > 0 && hi <= ((u64)1 << 28);
+}
+
 // Partition phase of a join: leaves ctx->cur_* describing partitioned R and S.
 // before_S (optional, consumed by the first call that gets it): invoked once, after the kernels that partition R have been
 // enqueued and before anything reads S -- rhj_join uploads S there, so that S crosses PCIe while R is being partitioned
@@ -919,6 +958,21 @@ int partition_phase(rhj_ctx *ctx, const void *d_R, u64 nR, const void *d_S, u64 
             RHJCHK(partition_relation_narrow2(ctx, d_R, nR, plan.bits1, plan.bits2, ctx->part_R.p, (u64 *)ctx->ps_R.p, nullptr, mix));
             RHJCHK(s_ready());
             RHJCHK(partition_relation_narrow2(ctx, d_S, nS, plan.bits1, plan.bits2, ctx->part_S.p, (u64 *)ctx->ps_S.p, nullptr, mix));
+        } else if (two_streams_ok(ctx, nR, nS, plan, before_S)) {
+            // Mid-size joins are launch-bound (a fused two-pass partition is ~11 short dependent launches per relation): R and S
+            // are independent until the join, so S is partitioned on a second stream, in a second set of scratch tables, while R
+            // runs on the first -- the gaps between one relation's launches are filled by the other's kernels.
+            if (!ctx->aux_stream) {
+                HIPCHK(ctx, hipStreamCreateWithFlags(&ctx->aux_stream, hipStreamNonBlocking));
+                for (int i = 0; i < 2; i++) HIPCHK(ctx, hipEventCreateWithFlags(&ctx->aux_ev[i], hipEventDisableTiming));
+            }
+            HIPCHK(ctx, hipEventRecord(ctx->aux_ev[0], ctx->stream));             // (the inputs, the cleared flag: everything so far)
+            HIPCHK(ctx, hipStreamWaitEvent(ctx->aux_stream, ctx->aux_ev[0], 0));
+            const PartScratch s2 = second_scratch(ctx);
+            RHJCHK(partition_relation_fused(ctx, d_R, nR, plan.bits1, plan.bits2, ctx->part_R.p, (u64 *)ctx->ps_R.p, ctx->cur_narrow, mix));
+            RHJCHK(partition_relation_fused(ctx, d_S, nS, plan.bits1, plan.bits2, ctx->part_S.p, (u64 *)ctx->ps_S.p, ctx->cur_narrow, mix, &s2));
+            HIPCHK(ctx, hipEventRecord(ctx->aux_ev[1], ctx->aux_stream));
+            HIPCHK(ctx, hipStreamWaitEvent(ctx->stream, ctx->aux_ev[1], 0));
         } else if (ctx->cur_narrow) {
             RHJCHK(partition_relation_fused(ctx, d_R, nR, plan.bits1, plan.bits2, ctx->part_R.p, (u64 *)ctx->ps_R.p, ctx->cur_narrow, mix));
             RHJCHK(s_ready());
@@ -1273,7 +1327,8 @@ int rhj_release_workspace(rhj_ctx *ctx)
                      &ctx->unit_start_b, &ctx->unit_hist_b, &ctx->unit_base_b, &ctx->scan_tmp_b, &ctx->tasks,
                      &ctx->counters, &ctx->out_pairs, &ctx->small_out, &ctx->hist_tmp, &ctx->scan_tmp, &ctx->hist2,
                      &ctx->grp_rng, &ctx->unit_start2, &ctx->narrow_flag, &ctx->seg_rng, &ctx->tag_base,
-                     &ctx->shard_ps[0], &ctx->shard_ps[1], &ctx->shard_mm, &ctx->shard_wide, &ctx->shard_peer_tab, &ctx->fuse_ctl, &ctx->b_in[0], &ctx->b_out[0], &ctx->b_cnt[0],
+                     &ctx->shard_ps[0], &ctx->shard_ps[1], &ctx->shard_mm, &ctx->shard_wide, &ctx->shard_peer_tab, &ctx->fuse_ctl, &ctx->hist2_b, &ctx->grp_rng_b,
+                     &ctx->unit_start2_b, &ctx->ps_1_b, &ctx->part_tmp_b, &ctx->b_in[0], &ctx->b_out[0], &ctx->b_cnt[0],
                      &ctx->b_in[1], &ctx->b_out[1], &ctx->b_cnt[1]};
     ctx->fuse_clean = false;
     for (DevBuf *b : all) release(*b);
@@ -1301,6 +1356,8 @@ void rhj_destroy(rhj_ctx *ctx)
     for (hipEvent_t ev : ctx->prof.pool) (void)hipEventDestroy(ev);
     for (int i = 0; i < 2; i++) if (ctx->up_ev[i]) (void)hipEventDestroy(ctx->up_ev[i]);
     if (ctx->copy_stream) (void)hipStreamDestroy(ctx->copy_stream);
+    if (ctx->aux_stream) (void)hipStreamDestroy(ctx->aux_stream);
+    for (int i = 0; i < 2; i++) if (ctx->aux_ev[i]) (void)hipEventDestroy(ctx->aux_ev[i]);
     if (ctx->down_stream) (void)hipStreamDestroy(ctx->down_stream);
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
     delete ctx->pool;

@@ -829,15 +829,27 @@ int partition_relation(rhj_ctx *ctx, const void *d_in, u64 n, int passes, int b1
 // Average build partition larger than one 4224-tuple table (an explicit plan with too few bits, or more than 2^30
 // tuples): the compact-table kernel when the plan removed enough payload bits for 48-bit keys, else 8448-tuple
 // chunks.  The compact-table kernel keeps a task's probe rowIDs in registers, so a task is at most that many tuples.
-int choose_join_kind(const rhj_ctx *ctx, u64 nR, u64 nS, u64 nparts, int radix_bits, bool narrow = false)
+// allow13: plans of 13-15 bits may take the compact-table kernel with 13-bit arrival indices (keys of up to 51 bits) for
+// average partitions of 2-5 K tuples (not the multi-GPU receiver, whose sender tags the one-table kernel resolves).
+int choose_join_kind(const rhj_ctx *ctx, u64 nR, u64 nS, u64 nparts, int radix_bits, bool narrow = false, bool allow13 = true)
 {
     const u64 nbuild = nR < nS ? nR : nS;
+    if (radix_bits < join_ct_min_radix_bits(JK_CT) && radix_bits >= join_ct_min_radix_bits(JK_CT_G13) && allow13 &&
+        (ctx->opt_big_kernel < 0 || ctx->opt_big_kernel == JK_CT_G13)) {
+        static const bool on = env_u64("RHJ_CT13", 1, 0, 1) != 0;              // tuning aid: 0 = the one-table kernel as before
+        const u64 nprobe13 = nR < nS ? nS : nR, ab13 = nbuild / nparts, ap13 = nprobe13 / nparts;
+        const bool fits13 = ab13 <= (u64)join_table_tuples(JK_CT_G13) * 15 / 16 && ap13 <= (u64)join_probe_split(JK_CT_G13) * 15 / 16 &&
+                            ab13 <= (u64)CT_GUARDED_UPTO && ap13 <= (u64)CT_GUARDED_UPTO;
+        if ((ctx->opt_big_kernel == JK_CT_G13 && ctx->opt_big_tables == 1) ||
+            (on && ctx->opt_big_tables < 0 && ab13 > (u64)CT_GUARDED_FROM && fits13))
+            return JK_CT_G13;
+    }
     // ... and from half a table on when the plan allows the compact-table kernel: its 6144-entry geometry with row guards
     // handles a tuple in two thirds of the one-table kernel's time ([measured] 1.5 - 2.7 * 10^8 tuples under 16 bits)
-    const bool ct_ok = radix_bits >= join_ct_min_radix_bits() && ctx->opt_big_kernel != JK_BKT_BIG;
+    const bool ct_ok = radix_bits >= join_ct_min_radix_bits(JK_CT) && ctx->opt_big_kernel != JK_BKT_BIG;
     const u64 big_from = ct_ok ? (u64)CT_GUARDED_FROM : (u64)BJ_CHUNK;
     if (!(ctx->opt_big_tables == 1 || (ctx->opt_big_tables < 0 && nbuild / nparts > big_from))) return JK_BKT;
-    if (radix_bits < join_ct_min_radix_bits() || ctx->opt_big_kernel == JK_BKT_BIG) return JK_BKT_BIG;
+    if (radix_bits < join_ct_min_radix_bits(JK_CT) || ctx->opt_big_kernel == JK_BKT_BIG) return JK_BKT_BIG;
     if (jk_is_ct(ctx->opt_big_kernel) && !jk_ct_narrow_only(ctx->opt_big_kernel)) return ctx->opt_big_kernel;
     if (ctx->opt_big_kernel == JK_CT_WIDE) return narrow ? JK_CT_WIDE : JK_CT_13;
     if (ctx->opt_big_kernel == JK_CT_HALF_WIDE) return narrow ? JK_CT_HALF_WIDE : JK_CT_HALF;
@@ -1002,14 +1014,14 @@ int partition_phase(rhj_ctx *ctx, const void *d_R, u64 nR, const void *d_S, u64 
 int join_phase_on(rhj_ctx *ctx, const void *d_Rp, const u64 *d_psR, u64 nR, const void *d_Sp, const u64 *d_psS,
                   u64 nS, u64 nparts, int radix_bits, u32 probe_split, void *d_out, u64 cap, u64 *out_count, bool narrow = false,
                   const u64 *d_tag_base = nullptr, bool allow_direct = true, bool check_radix = false, bool keep_count = false,
-                  bool enqueue_only = false)
+                  bool enqueue_only = false, bool allow13 = true)
 {
     // keep_count: the result counter goes on from where the previous join on this context left it (the pairs of several joins
     // land behind one another in d_out); enqueue_only: no read-back, the caller collects the counters itself
     if (probe_split == 0) probe_split = 32768;
     // a task addresses its build range with 32 bits; k_make_tasks reports any partition whose build side is larger
     // (counters[5], checked below) whatever the plan
-    const int kind = choose_join_kind(ctx, nR, nS, nparts, radix_bits, narrow);
+    const int kind = choose_join_kind(ctx, nR, nS, nparts, radix_bits, narrow, allow13);
     if (narrow && kind != JK_BKT && !jk_is_ct(kind))
         return fail(ctx, RHJ_E_INVALID, "no bucket-join kernel for narrow partitions under this plan");
     if (join_probe_split(kind) && probe_split > join_probe_split(kind)) probe_split = join_probe_split(kind);
@@ -2268,7 +2280,7 @@ int rhj_shard_plan(uint64_t nR, uint64_t nS, const rhj_opts *in, rhj_opts *resol
     if (o.bits1 < tag_bits()) return 0;
     rhj_ctx probe;                                      // default options: which kernel would join partitions of this size
     const int tb = o.bits1 + o.bits2;
-    const int kind = choose_join_kind(&probe, nR, nS, (u64)1 << tb, tb);
+    const int kind = choose_join_kind(&probe, nR, nS, (u64)1 << tb, tb, false, false);
     if (kind == JK_BKT) return RHJ_SHARD_TAGGED;
     if (jk_is_ct(kind) && !jk_ct_narrow_only(kind)) return RHJ_SHARD_GLOBAL16;
     return 0;
@@ -2498,7 +2510,7 @@ int rhj_shard_join(rhj_ctx *ctx, rhj_pair *d_out, uint64_t out_capacity, uint64_
     const int mode = ctx->shard_mode[0];
     const int tb = ctx->shard_plan.bits1 + ctx->shard_plan.bits2;
     const bool narrow = mode != RHJ_SHARD_GLOBAL16;
-    if (mode == RHJ_SHARD_TAGGED && choose_join_kind(ctx, mR, mS, (u64)1 << tb, tb) != JK_BKT)
+    if (mode == RHJ_SHARD_TAGGED && choose_join_kind(ctx, mR, mS, (u64)1 << tb, tb, false, false) != JK_BKT)
         return fail(ctx, RHJ_E_INVALID, "rhj_shard_join: partitions this large need RHJ_SHARD_GLOBAL16 (see rhj_shard_plan)");
     ctx->cur_narrow = narrow ? 2 : 0;
     ctx->last.passes = 2;
@@ -2506,7 +2518,7 @@ int rhj_shard_join(rhj_ctx *ctx, rhj_pair *d_out, uint64_t out_capacity, uint64_
     ctx->last.bits2 = ctx->shard_plan.bits2;
     int rc = join_phase_on(ctx, ctx->part_R.p, (const u64 *)ctx->ps_R.p, mR, ctx->part_S.p, (const u64 *)ctx->ps_S.p, mS,
                            (u64)1 << tb, tb, (u32)ctx->shard_plan.probe_split, d_out, d_out ? out_capacity : 0, (u64 *)out_count, narrow,
-                           mode == RHJ_SHARD_TAGGED ? (const u64 *)ctx->tag_base.p : nullptr, false);
+                           mode == RHJ_SHARD_TAGGED ? (const u64 *)ctx->tag_base.p : nullptr, false, false, false, false, false);
     if (rc == RHJ_RETRY_WIDE) return fail(ctx, RHJ_E_HIP, "rhj_shard_join: unexpected wide-rowID flag");
     RHJCHK(rc);
     if (ctx->shard_wide.p) {                               // what this context's own rhj_shard_split calls met (the stream is idle here)

@@ -1938,6 +1938,9 @@ constexpr int CTM_CHUNK = 12288, CTM_EPT = 12, CTM_BUCKET_BITS = 14, CTHM_BUCKET
 constexpr int CTHM_CHUNK = 6144;                    // ... and at half size (512 threads, two workgroups per CU): 4.2 - 5.8 K-tuple partitions
 constexpr u32 CT_NONE = 0xFFFFu;
 constexpr int CT_MIN_RADIX_BITS = 16;       // keys must fit 48 bits
+// JK_CT_G13: the 6144-entry geometry with row guards and 13-bit arrival indices: keys of up to 51 bits, i.e. plans of 13-15
+// radix bits (1.6 * 10^7 ... 1.3 * 10^8 tuples per side), whose 2-4 K-tuple partitions the one-table kernel served until round 4
+constexpr int CT13_KB = 13, CT13_MIN_RADIX_BITS = 64 - (64 - CT13_KB);
 constexpr u32 CT_MASK_BITS = 16;            // a probe records its matches as a bit mask over a bucket of at most this many entries
 
 // 32-bit Fibonacci hash of the folded key: one quarter-rate multiply instead of the four of a 64-bit product (the probe
@@ -1974,7 +1977,9 @@ constexpr int CT_NSTAMP = 16;
 
 // skip (optional): a device word that is non-zero when this join is going to be repeated in another format (a rowID did
 // not fit the narrow format): nothing to do then.
-template <int THREADS, int CHUNK, int BBITS, int EPT, bool STAMPS, bool NARROW, bool GUARD = false>
+// KB: bits of the arrival index in a table entry {key | index}: 16 by default (keys of 48 bits: plans that remove >= 16 payload bits);
+// 13 for the 6144-entry geometry under plans of 13-15 bits (keys of up to 51 bits: the partitions of 1.6 * 10^7 ... 1.3 * 10^8 tuples)
+template <int THREADS, int CHUNK, int BBITS, int EPT, bool STAMPS, bool NARROW, bool GUARD = false, int KB = 16>
 __global__ void __launch_bounds__(THREADS, THREADS * (CHUNK <= 8960 ? 2 : 1) / 256)   // wavefronts per SIMD: 2 (256 registers per lane) or 4 (128)
 k_join_ct(const RelView<NARROW> R, const RelView<NARROW> S, const JoinTask *__restrict__ tasks,
           const u32 *__restrict__ ntasks, int radix_bits, Pair *__restrict__ out, u64 out_capacity,
@@ -1989,6 +1994,8 @@ k_join_ct(const RelView<NARROW> R, const RelView<NARROW> S, const JoinTask *__re
     stamp();                                                                 // 0: start
     constexpr int NB = 1 << BBITS;
     constexpr int NW = THREADS / 64;
+    constexpr u32 KM = (1u << KB) - 1u;                             // index part of an entry
+    static_assert(CHUNK <= (1 << KB), "the arrival index of every table entry must fit KB bits");
     constexpr int BPT = (CHUNK + THREADS - 1) / THREADS;            // build tuples per thread
     constexpr int BB = BPT;                                         // build loads in flight per lane: the whole build side
     constexpr int WPT = NB / 2 / THREADS;                           // packed counter words per thread in the scan
@@ -2063,7 +2070,7 @@ k_join_ct(const RelView<NARROW> R, const RelView<NARROW> S, const JoinTask *__re
                 if (!USED(k, nc)) continue;
                 const u64 key = bt[k - k0] >> rb;
                 const u32 h = k < nvb ? ct_bucket<BBITS>(key) : (u32)NB + 2u, sh = (h & 1u) * 16u;   // NB + 2: a padding word
-                kr[k] = (key << 16) | ((atomicAdd(&off32[h >> 1], 1u << sh) >> sh) & 0xFFFFu);
+                kr[k] = (key << KB) | ((atomicAdd(&off32[h >> 1], 1u << sh) >> sh) & 0xFFFFu);     // (the rank inside a bucket: < CHUNK <= 2^KB)
             }
         }
         stamp();                                                             // 1: build side loaded and counted
@@ -2091,9 +2098,9 @@ k_join_ct(const RelView<NARROW> R, const RelView<NARROW> S, const JoinTask *__re
 #pragma unroll
             for (int k = 0; k < BPT; k++) {
                 if (!USED(k, nc)) { if (!(k & 1)) ppos[k >> 1] = 0; continue; }
-                const u64 key = kr[k] >> 16;
-                const u32 pos = off16[ct_bucket<BBITS>(key)] + ((u32)kr[k] & 0xFFFFu);
-                *(k < nvp ? &ent[pos] : dummy) = (key << 16) | (u64)((u32)k * THREADS + tp);
+                const u64 key = kr[k] >> KB;
+                const u32 pos = off16[ct_bucket<BBITS>(key)] + ((u32)kr[k] & KM);
+                *(k < nvp ? &ent[pos] : dummy) = (key << KB) | (u64)((u32)k * THREADS + tp);
                 if (k & 1) ppos[k >> 1] |= pos << 16; else ppos[k >> 1] = pos;
             }
         }
@@ -2132,7 +2139,7 @@ k_join_ct(const RelView<NARROW> R, const RelView<NARROW> S, const JoinTask *__re
                 prid[k] = ring[t % DEPTH][s].key;
                 const u64 key = ring[t % DEPTH][s].payload >> rb;
                 const u32 h = ct_bucket<BBITS>(key);
-                khi[s] = (u32)(key >> 16); klo[s] = (u32)key << 16;
+                khi[s] = (u32)(key >> (32 - KB)); klo[s] = (u32)key << KB;
                 lo[s] = off16[h]; m[s] = 0;
                 len[s] = k < nv ? off16[h + 1] - lo[s] : 0u;
                 maxlen = len[s] > maxlen ? len[s] : maxlen;
@@ -2155,7 +2162,7 @@ k_join_ct(const RelView<NARROW> R, const RelView<NARROW> S, const JoinTask *__re
                         // (no `j < len` here: an entry of another bucket has another key; what lies behind the table's end is
                         // masked off below)
                         const u32 xl = (u32)e[s] ^ klo[s];
-                        if ((u32)(e[s] >> 32) == khi[s] && xl < 0x10000u) m[s] |= 0x10000u << j;
+                        if ((u32)(e[s] >> 32) == khi[s] && xl <= KM) m[s] |= 0x10000u << j;
                     }
                 }
 #pragma unroll
@@ -2187,7 +2194,7 @@ k_join_ct(const RelView<NARROW> R, const RelView<NARROW> S, const JoinTask *__re
             const bool coop = heavy != 0 && __popcll(heavy) <= BJ_HEAVY_LANES;
             const bool serial = !coop || hi - lo <= BJ_HEAVY;
             u32 c = 0;
-            if (serial) for (u32 j = lo; j < hi; j++) c += ((ent[j] >> 16) == key) ? 1u : 0u;
+            if (serial) for (u32 j = lo; j < hi; j++) c += ((ent[j] >> KB) == key) ? 1u : 0u;
             if (coop) {
                 unsigned long long hv = heavy;
                 while (hv) {
@@ -2197,7 +2204,7 @@ k_join_ct(const RelView<NARROW> R, const RelView<NARROW> S, const JoinTask *__re
                     const u32 l = __builtin_amdgcn_readlane(lo, leader), hh = __builtin_amdgcn_readlane(hi, leader);
                     u32 tot = 0;
                     for (u32 j = l; j < hh; j += 64) {
-                        const bool mt = (j + lane < hh) && (ent[j + lane] >> 16) == lkey;
+                        const bool mt = (j + lane < hh) && (ent[j + lane] >> KB) == lkey;
                         tot += (u32)__popcll(__ballot(mt));
                     }
                     if (lane == leader) c = tot;
@@ -2214,9 +2221,9 @@ k_join_ct(const RelView<NARROW> R, const RelView<NARROW> S, const JoinTask *__re
             if (c && serial) {
                 for (u32 j = lo; j < hi; j++) {
                     const u64 e = ent[j];
-                    if ((e >> 16) == key) {
+                    if ((e >> KB) == key) {
                         if (o < out_capacity) {
-                            const u64 br = B.rowid(cb + ((u32)e & 0xFFFFu));
+                            const u64 br = B.rowid(cb + ((u32)e & KM));
                             Pair pr;
                             if (build_is_S) { pr.r = pt.key; pr.s = br; } else { pr.r = br; pr.s = pt.key; }
                             out[o] = pr;
@@ -2236,11 +2243,11 @@ k_join_ct(const RelView<NARROW> R, const RelView<NARROW> S, const JoinTask *__re
                     for (u32 j = l; j < hh; j += 64) {
                         u64 e = 0;
                         bool mt = false;
-                        if (j + lane < hh) { e = ent[j + lane]; mt = (e >> 16) == lkey; }
+                        if (j + lane < hh) { e = ent[j + lane]; mt = (e >> KB) == lkey; }
                         const unsigned long long bal = __ballot(mt);
                         const u64 dst = ob + (u64)__popcll(bal & lt);
                         if (mt && dst < out_capacity) {
-                            const u64 br = B.rowid(cb + ((u32)e & 0xFFFFu));
+                            const u64 br = B.rowid(cb + ((u32)e & KM));
                             Pair pr;
                             if (build_is_S) { pr.r = lprid; pr.s = br; } else { pr.r = br; pr.s = lprid; }
                             out[dst] = pr;
@@ -2499,14 +2506,14 @@ u32 join_probe_split(int kind)
 {
     return kind == JK_CT || kind == JK_CT_13 ? (u32)(CT_THREADS * CT_EPT) : kind == JK_CT_HALF ? (u32)(CTH_THREADS * CT_EPT) :
            kind == JK_CT_WIDE ? (u32)(CT_THREADS * CT_EPT_WIDE) : kind == JK_CT_HALF_WIDE ? (u32)(CTH_THREADS * CT_EPT_WIDE) :
-           kind == JK_CT_MID ? (u32)(CT_THREADS * CTM_EPT) : kind == JK_CT_HALF_MID || kind == JK_CT_HALF_MID_G ? (u32)(CTH_THREADS * CTM_EPT) : 0u;
+           kind == JK_CT_MID ? (u32)(CT_THREADS * CTM_EPT) : kind == JK_CT_HALF_MID || kind == JK_CT_HALF_MID_G || kind == JK_CT_G13 ? (u32)(CTH_THREADS * CTM_EPT) : 0u;
 }
 u32 join_table_tuples(int kind)
 {
     return kind == JK_CT ? (u32)CT_CHUNK : kind == JK_CT_13 || kind == JK_CT_WIDE ? (u32)CT13_CHUNK : kind == JK_CT_HALF ? (u32)CTH_CHUNK : kind == JK_CT_HALF_WIDE ? (u32)CTHW_CHUNK :
-           kind == JK_CT_MID ? (u32)CTM_CHUNK : kind == JK_CT_HALF_MID || kind == JK_CT_HALF_MID_G ? (u32)CTHM_CHUNK : kind == JK_BKT_BIG ? (u32)BJ2_CHUNK : (u32)BJ_CHUNK;
+           kind == JK_CT_MID ? (u32)CTM_CHUNK : kind == JK_CT_HALF_MID || kind == JK_CT_HALF_MID_G || kind == JK_CT_G13 ? (u32)CTHM_CHUNK : kind == JK_BKT_BIG ? (u32)BJ2_CHUNK : (u32)BJ_CHUNK;
 }
-int join_ct_min_radix_bits() { return CT_MIN_RADIX_BITS; }
+int join_ct_min_radix_bits(int kind) { return kind == JK_CT_G13 ? CT13_MIN_RADIX_BITS : CT_MIN_RADIX_BITS; }
 
 static size_t bj_lds_bytes(int threads, int chunk, int bbits)
 {
@@ -2580,6 +2587,8 @@ static void allow_big_lds()
     SET_LDS((k_join_ct<CTH_THREADS, CTHM_CHUNK, CTHM_BUCKET_BITS, CTM_EPT, false, false>), ct_lds_bytes(CTH_THREADS, CTHM_CHUNK, CTHM_BUCKET_BITS));
     SET_LDS((k_join_ct<CTH_THREADS, CTHM_CHUNK, CTHM_BUCKET_BITS, CTM_EPT, false, true, true>), ct_lds_bytes(CTH_THREADS, CTHM_CHUNK, CTHM_BUCKET_BITS));
     SET_LDS((k_join_ct<CTH_THREADS, CTHM_CHUNK, CTHM_BUCKET_BITS, CTM_EPT, false, false, true>), ct_lds_bytes(CTH_THREADS, CTHM_CHUNK, CTHM_BUCKET_BITS));
+    SET_LDS((k_join_ct<CTH_THREADS, CTHM_CHUNK, CTHM_BUCKET_BITS, CTM_EPT, false, true, true, CT13_KB>), ct_lds_bytes(CTH_THREADS, CTHM_CHUNK, CTHM_BUCKET_BITS));
+    SET_LDS((k_join_ct<CTH_THREADS, CTHM_CHUNK, CTHM_BUCKET_BITS, CTM_EPT, false, false, true, CT13_KB>), ct_lds_bytes(CTH_THREADS, CTHM_CHUNK, CTHM_BUCKET_BITS));
     SET_LDS((k_join_ct<CTH_THREADS, CTHW_CHUNK, CTHW_BUCKET_BITS, CT_EPT_WIDE, false, true>), ct_lds_bytes(CTH_THREADS, CTHW_CHUNK, CTHW_BUCKET_BITS));
     SET_LDS((k_join_bkt<BJ_THREADS, BJ_CHUNK, BJ_BUCKET_BITS, BJ_EPT, false, true, true>), bj_lds_bytes(BJ_THREADS, BJ_CHUNK, BJ_BUCKET_BITS));
     SET_LDS(k_scatter_wc_n<WC_THREADS>, wc_lds_bytes(WC_MAX_BITS, WC_THREADS));
@@ -2958,6 +2967,10 @@ void launch_join(hipStream_t st, const void *d_R, const u64 *d_startR, const voi
         else if (kind == JK_CT_13) LAUNCH_CT_N(CT_THREADS, CT13_CHUNK, CT13_BUCKET_BITS, CT_EPT);
         else if (kind == JK_CT_MID) LAUNCH_CT_N(CT_THREADS, CTM_CHUNK, CTM_BUCKET_BITS, CTM_EPT);
         else if (kind == JK_CT_HALF_MID) LAUNCH_CT_N(CTH_THREADS, CTHM_CHUNK, CTHM_BUCKET_BITS, CTM_EPT);
+        else if (kind == JK_CT_G13)
+            hipLaunchKernelGGL((k_join_ct<CTH_THREADS, CTHM_CHUNK, CTHM_BUCKET_BITS, CTM_EPT, false, true, true, CT13_KB>), dim3(grid), dim3(CTH_THREADS),
+                               ct_lds_bytes(CTH_THREADS, CTHM_CHUNK, CTHM_BUCKET_BITS), st, nR, nS, d_tasks, d_ntasks, radix_bits, o, out_capacity,
+                               d_out_count, (u64 *)nullptr, 0u, d_skip);
         else if (kind == JK_CT_HALF_MID_G)
             hipLaunchKernelGGL((k_join_ct<CTH_THREADS, CTHM_CHUNK, CTHM_BUCKET_BITS, CTM_EPT, false, true, true>), dim3(grid), dim3(CTH_THREADS),
                                ct_lds_bytes(CTH_THREADS, CTHM_CHUNK, CTHM_BUCKET_BITS), st, nR, nS, d_tasks, d_ntasks, radix_bits, o, out_capacity,
@@ -2981,6 +2994,12 @@ void launch_join(hipStream_t st, const void *d_R, const u64 *d_startR, const voi
     }
     if (kind == JK_CT_HALF_MID) {
         hipLaunchKernelGGL((k_join_ct<CTH_THREADS, CTHM_CHUNK, CTHM_BUCKET_BITS, CTM_EPT, false, false>), dim3(grid), dim3(CTH_THREADS),
+                           ct_lds_bytes(CTH_THREADS, CTHM_CHUNK, CTHM_BUCKET_BITS), st, vR, vS, d_tasks,
+                           d_ntasks, radix_bits, (Pair *)d_out, out_capacity, d_out_count, (u64 *)nullptr, 0u, (const u32 *)nullptr);
+        return;
+    }
+    if (kind == JK_CT_G13) {
+        hipLaunchKernelGGL((k_join_ct<CTH_THREADS, CTHM_CHUNK, CTHM_BUCKET_BITS, CTM_EPT, false, false, true, CT13_KB>), dim3(grid), dim3(CTH_THREADS),
                            ct_lds_bytes(CTH_THREADS, CTHM_CHUNK, CTHM_BUCKET_BITS), st, vR, vS, d_tasks,
                            d_ntasks, radix_bits, (Pair *)d_out, out_capacity, d_out_count, (u64 *)nullptr, 0u, (const u32 *)nullptr);
         return;

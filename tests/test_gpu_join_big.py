@@ -18,7 +18,7 @@ from radixhashjoin_amd import Engine, Opts
 from radixhashjoin_amd.binding import GEN_CONST, GEN_R, GEN_S_UNIFORM, GEN_S_ZIPF, unmix64
 
 pytestmark = pytest.mark.gpu
-BKT_BIG, CT, CT_HALF, CT_WIDE, CT_HALF_WIDE, CT_MID, CT_HALF_MID, CT_13, CT_HALF_MID_G = 1, 2, 3, 4, 5, 6, 7, 8, 9
+BKT_BIG, CT, CT_HALF, CT_WIDE, CT_HALF_WIDE, CT_MID, CT_HALF_MID, CT_13, CT_HALF_MID_G, CT_G13 = 1, 2, 3, 4, 5, 6, 7, 8, 9, 10
 
 
 def _forced(param):
@@ -41,10 +41,12 @@ def big(request):
 
 # the geometries added in round 3 (same kernel template, other table size / slot rows): a shorter list of cases, chosen at
 # their table and task boundaries, plus duplicates, long buckets and the 17-18-bit plans
-@pytest.fixture(scope="module", params=[(CT_WIDE, 2), (CT_HALF_WIDE, 2), (CT_MID, 0), (CT_MID, 2), (CT_HALF_MID, 2), (CT_13, 0), (CT_13, 2), (CT_HALF_MID_G, 0), (CT_HALF_MID_G, 2)],
+@pytest.fixture(scope="module", params=[(CT_WIDE, 2), (CT_HALF_WIDE, 2), (CT_MID, 0), (CT_MID, 2), (CT_HALF_MID, 2), (CT_13, 0), (CT_13, 2), (CT_HALF_MID_G, 0), (CT_HALF_MID_G, 2),
+                                        (CT_G13, 0), (CT_G13, 2)],
                 ids=["compact_table_20slots_narrow2", "compact_table_half_20slots_narrow2", "compact_table_mid",
                      "compact_table_mid_narrow2", "compact_table_half_mid_narrow2", "compact_table_8192_buckets",
-                     "compact_table_8192_buckets_narrow2", "compact_table_half_mid_row_guards", "compact_table_half_mid_row_guards_narrow2"])
+                     "compact_table_8192_buckets_narrow2", "compact_table_half_mid_row_guards", "compact_table_half_mid_row_guards_narrow2",
+                     "compact_table_13bit_index", "compact_table_13bit_index_narrow2"])
 def geom(request):
     e = _forced(request.param)
     yield e
@@ -373,3 +375,48 @@ def test_a_huge_probe_split_from_the_caller(engine, oracle, plan):
     got = engine.join(R, S, opts=plan)
     exp = oracle.join(R, S)
     assert len(got) == len(exp) and np.array_equal(sorted_pairs(got), sorted_pairs(exp))
+
+
+@pytest.mark.parametrize("narrow", [0, 2])
+@pytest.mark.parametrize("plan", [Opts(2, 7, 6), Opts(2, 7, 7), Opts(2, 8, 7), Opts(2, 8, 8)])
+def test_13_bit_index_compact_table_under_13_to_16_bit_plans(oracle, plan, narrow):
+    """k_join_ct<.., KB = 13>: table entries {key of up to 51 bits | 13-bit arrival index}, what plans of 13-15 radix bits take for
+    partitions of 2-5 K tuples since round 4.  Forced here onto few, large partitions (chunks of the 6144-entry table, several
+    probe tasks per partition), duplicates on both sides, long buckets, unmatched probes; and chosen BY ITSELF for a 7+7-bit join
+    whose partitions average 2.4 K tuples."""
+    tb = plan.bits1 + plan.bits2
+    e = Engine(0)
+    try:
+        e.set_option("join.big_tables", 1)
+        e.set_option("join.big_kernel", CT_G13)
+        e.set_option("partition.narrow", narrow)
+        e.narrow = narrow
+        rng = np.random.default_rng(tb * 10 + narrow)
+        for nR, nS, nlow, dup in ((30_000, 50_000, 3, 1), (6_144, 6_144, 1, 1), (6_145, 6_150, 1, 1), (40_000, 25_000, 5, 4), (2_500, 9_000, 2, 1)):
+            vals = rng.permutation(1 << 22)[:max(nR // dup, 1)].astype(np.uint64)
+            rv = vals[rng.integers(0, len(vals), nR)] if dup > 1 else vals[:nR]
+            lows = np.random.default_rng(nlow).permutation(1 << tb)[:nlow].astype(np.uint64)
+            craft = lambda v: unmix64((v << np.uint64(tb)) | lows[(v % np.uint64(nlow)).astype(np.int64)])
+            R = rel(rng, nR, craft(rv))
+            sv = rv[rng.integers(0, nR, nS)]
+            sv[::41] ^= np.uint64(1 << 21)                                 # some probes match another value or nothing
+            S = rel(rng, nS, craft(sv), key0=1 << 31)
+            got = e.join(R, S, opts=plan)
+            exp = oracle.join(R, S)
+            assert len(got) == len(exp) and np.array_equal(sorted_pairs(got), sorted_pairs(exp))
+            assert e.info("last.join_kernel") == CT_G13
+        if (plan.bits1, plan.bits2) == (7, 7):                               # the automatic choice: 40M tuples, 2.4 K per partition
+            e.set_option("join.big_tables", -1)
+            e.set_option("join.big_kernel", -1)
+            e.set_option("partition.narrow", -1)
+            n = 40_000_000
+            dR, dS, dO = e.alloc(16 * n), e.alloc(16 * n), e.alloc(16 * n)
+            e.generate(GEN_R, dR, n, 0, n)
+            e.generate(GEN_S_UNIFORM, dS, n, 0, n, seed=5)
+            exp_n, exp_c = e.expected_pkfk(dS, n)
+            assert e.join_dev(dR, n, dS, n, dO, n) == exp_n
+            assert e.pairs_checksum(dO, n) == exp_c
+            t = e.timings()
+            assert (t["passes"], t["bits1"] + t["bits2"]) == (2, 14) and e.info("last.join_kernel") == CT_G13
+    finally:
+        e.close()

@@ -1,3 +1,7 @@
+#!/usr/bin/env python3
+"""tools/batch_time.py -- the 94 joins of small.work (sizes and match counts of tests/golden/small_joins.json, synthetic values) through
+rhj_join_batch with 0 / 1 / 3 / 5 / 7 helper threads (RHJ_BATCH_THREADS is read when a context first batches), next to 94 single
+rhj_join calls: wall ms of the C calls from ONE thread (development aid; run on the GPU box)."""
 import json, os, sys, time
 import numpy as np
 sys.path.insert(0, os.getcwd())

@@ -94,3 +94,42 @@ def test_join_batch_equals_the_golden_pair_sets(engine, small_joins):
         assert len(got[k + 2]) == 6_000_000 and len(np.unique(got[k + 2]["keyR"] * np.uint64(2_000) + got[k + 2]["keyS"])) == 6_000_000
         for (R, S, P), g in zip(cases[:5], got[k + 3:]):
             assert np.array_equal(sorted_pairs(g), sorted_pairs(P))
+
+
+def test_join_batch_from_several_threads_with_a_context_each(small_joins):
+    """eight host threads, eight contexts (MainScheduler.cpp:6-14), every one batching the golden joins and running one-pass joins
+    (three-launch path) in between: contexts share nothing, results stay the golden pair sets"""
+    import threading
+    from conftest import small_call_arrays
+    from oracle.pyoracle import sorted_pairs
+    from radixhashjoin_amd import Engine, Opts
+    meta, npz = small_joins
+    cases = [small_call_arrays(npz, i) for i, c in enumerate(meta) if c.get("vectors")]
+    want = [sorted_pairs(P) for _, _, P in cases]
+    rng = np.random.default_rng(9)
+    from oracle.pyoracle import TUPLE
+    big_R = np.empty(200_000, dtype=TUPLE); big_R["key"] = np.arange(200_000); big_R["payload"] = rng.permutation(200_000)
+    big_S = np.empty(300_000, dtype=TUPLE); big_S["key"] = np.arange(300_000); big_S["payload"] = rng.integers(0, 200_000, 300_000)
+    errors = []
+
+    def work(k):
+        try:
+            e = Engine(0)
+            for rep in range(3):
+                order = list(range(len(cases)))
+                np.random.default_rng(k * 10 + rep).shuffle(order)
+                got = e.join_batch([(cases[i][0], cases[i][1]) for i in order])
+                for i, g in zip(order, got):
+                    assert np.array_equal(sorted_pairs(g), want[i]), (k, rep, i)
+                p = e.join(big_R, big_S, opts=Opts(1, 6))
+                assert len(p) == 300_000 and np.array_equal(big_R["payload"][p["keyR"].astype(np.int64)], big_S["payload"][p["keyS"].astype(np.int64)])
+            e.close()
+        except Exception as ex:                                   # noqa: BLE001 -- reported by the main thread
+            errors.append((k, repr(ex)))
+
+    threads = [threading.Thread(target=work, args=(k,)) for k in range(8)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors, errors

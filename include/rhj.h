@@ -105,7 +105,7 @@ int  rhj_set_profiling(rhj_ctx *ctx, int enabled);
 /* tuning / test knobs; results never depend on them.  "join.big_tables": -1 (default) choose the bucket-join kernel by
  * the average build partition, 0 always the one-table kernel, 1 always an oversized-partition kernel;
  * "join.big_kernel": -1 automatic, 1 the chunked 16-byte-entry kernel, 2 / 3 the compact-table kernel at full / half size
- * where the plan allows, 4 / 5 the same with 20 instead of 16 probe slots per thread (narrow partitions; else 2 / 3), 6 / 7 the 12288-entry geometry and its half-size form (6144 entries), 8 the full-size table with half the buckets (17920 entries in 8192 buckets instead of 16352 in 16384), 9 the 6144-entry geometry skipping the slot rows a partition leaves empty, 10 the same with 13-bit arrival indices (keys of up to 51 bits: what plans of 13-15 radix bits take by themselves for partitions of 2-5 K tuples);
+ * where the plan allows, 4 / 5 the same with 20 instead of 16 probe slots per thread (narrow partitions; else 2 / 3), 6 / 7 the 12288-entry geometry and its half-size form (6144 entries), 8 the full-size table with half the buckets (17920 entries in 8192 buckets instead of 16352 in 16384), 9 the 6144-entry geometry skipping the slot rows a partition leaves empty, 10 the same with 13-bit arrival indices (keys of up to 51 bits: what plans of 13-15 radix bits take by themselves for partitions of 2-5 K tuples), 11 a 4096-entry table with 12-bit arrival indices (plans of 12 bits);
  * "partition.narrow": -1 automatic, 0 never, 1 / 2: inside a join with a two-pass plan, partitions (1) and the
  * intermediate of the two passes (2; the only level of 17-18-bit plans) are stored as {payload 8 B, rowID 4 B} while every
  * rowID is below 2^32 (a larger one is detected on the device -- by the first histogram kernel -- and THAT join repeats itself

@@ -834,6 +834,16 @@ int partition_relation(rhj_ctx *ctx, const void *d_in, u64 n, int passes, int b1
 int choose_join_kind(const rhj_ctx *ctx, u64 nR, u64 nS, u64 nparts, int radix_bits, bool narrow = false, bool allow13 = true)
 {
     const u64 nbuild = nR < nS ? nR : nS;
+    if (radix_bits < join_ct_min_radix_bits(JK_CT) && radix_bits >= join_ct_min_radix_bits(JK_CT_Q12) && allow13 &&
+        (ctx->opt_big_kernel < 0 || ctx->opt_big_kernel == JK_CT_Q12) && (radix_bits == join_ct_min_radix_bits(JK_CT_Q12) || ctx->opt_big_kernel == JK_CT_Q12)) {
+        // plans of exactly 12 bits (and a forced kernel 11 from 12 bits on): the 4096-entry table with 12-bit arrival indices
+        static const bool on12 = env_u64("RHJ_CT13", 1, 0, 1) != 0;
+        const u64 np12 = nR < nS ? nS : nR, ab12 = nbuild / nparts, ap12 = np12 / nparts;
+        const bool fits12 = ab12 <= (u64)join_table_tuples(JK_CT_Q12) * 15 / 16 && ap12 <= (u64)join_probe_split(JK_CT_Q12) * 15 / 16;
+        if ((ctx->opt_big_kernel == JK_CT_Q12 && ctx->opt_big_tables == 1) ||
+            (on12 && ctx->opt_big_tables < 0 && ab12 > (u64)CT_GUARDED_FROM && fits12))
+            return JK_CT_Q12;
+    }
     if (radix_bits < join_ct_min_radix_bits(JK_CT) && radix_bits >= join_ct_min_radix_bits(JK_CT_G13) && allow13 &&
         (ctx->opt_big_kernel < 0 || ctx->opt_big_kernel == JK_CT_G13)) {
         static const bool on = env_u64("RHJ_CT13", 1, 0, 1) != 0;              // tuning aid: 0 = the one-table kernel as before

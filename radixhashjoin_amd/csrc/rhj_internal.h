@@ -130,14 +130,14 @@ bool fused_two_pass_ok(int b1, int b2);
 // chunks, probe side re-read per chunk (any radix plan); JK_CT compact 8-byte entries, both sides read once
 // (plans that remove >= 16 payload bits)
 enum JoinKernel { JK_BKT = 0, JK_BKT_BIG = 1, JK_CT = 2, JK_CT_HALF = 3, JK_CT_WIDE = 4, JK_CT_HALF_WIDE = 5, JK_CT_MID = 6, JK_CT_HALF_MID = 7, JK_CT_13 = 8,
-                  JK_CT_HALF_MID_G = 9, JK_CT_G13 = 10, JK_LAST = JK_CT_G13 };
+                  JK_CT_HALF_MID_G = 9, JK_CT_G13 = 10, JK_CT_Q12 = 11, JK_LAST = JK_CT_Q12 };
 inline bool jk_is_ct(int k) { return k >= JK_CT && k <= JK_LAST; }                           // a compact-table geometry (48-bit keys: needs >= 16 radix bits)
 inline bool jk_ct_narrow_only(int k) { return k == JK_CT_WIDE || k == JK_CT_HALF_WIDE; }    // 20 probe slots: {payload, rowID} partitions only
 // _WIDE: 20 probe slots per thread (narrow format only); _MID: a 12288-entry table and 12 slots per thread (partitions of 8.4 - 11.5 K);
 // _HALF_MID: the same at half size, 6144 entries, 512 threads, two workgroups per CU (partitions of 4.2 - 5.8 K)
 u32 join_probe_split(int kind);      // probe tuples per task the kernel holds at most (0: no limit of its own)
 u32 join_table_tuples(int kind);     // build tuples per LDS table
-int join_ct_min_radix_bits(int kind = JK_CT);   // 16: keys of 48 bits beside a 16-bit arrival index; JK_CT_G13: 13 (51 + 13 bits)
+int join_ct_min_radix_bits(int kind = JK_CT);   // 16: keys of 48 bits beside a 16-bit arrival index; JK_CT_G13: 13 (51 + 13 bits); JK_CT_Q12: 12
 // in_narrow: d_in is a payload array (u64).  key_base / d_wide (16-byte input): d_wide (may be null) is OR-ed with 1 when some
 // rowID - key_base does not fit 32 bits.  d_unit_rng (may be null): explicit pass-1 units (launch_seg_units).
 void launch_hist2d_units(hipStream_t st, const void *d_in, bool in_narrow, u64 n, u64 L, u32 units, int b1, int b2,

@@ -1941,6 +1941,9 @@ constexpr int CT_MIN_RADIX_BITS = 16;       // keys must fit 48 bits
 // JK_CT_G13: the 6144-entry geometry with row guards and 13-bit arrival indices: keys of up to 51 bits, i.e. plans of 13-15
 // radix bits (1.6 * 10^7 ... 1.3 * 10^8 tuples per side), whose 2-4 K-tuple partitions the one-table kernel served until round 4
 constexpr int CT13_KB = 13, CT13_MIN_RADIX_BITS = 64 - (64 - CT13_KB);
+// JK_CT_Q12: a 4096-entry table with 12-bit arrival indices (keys of up to 52 bits) in 4096 buckets, 8 + 8 slot rows per thread, row
+// guards, 41 KiB of LDS: plans of exactly 12 bits (8.4 * 10^6 ... 1.6 * 10^7 tuples per side, partitions of 2-3.8 K tuples)
+constexpr int CTQ_CHUNK = 4096, CTQ_BUCKET_BITS = 12, CTQ_EPT = 8, CTQ_KB = 12;
 constexpr u32 CT_MASK_BITS = 16;            // a probe records its matches as a bit mask over a bucket of at most this many entries
 
 // 32-bit Fibonacci hash of the folded key: one quarter-rate multiply instead of the four of a 64-bit product (the probe
@@ -2506,14 +2509,16 @@ u32 join_probe_split(int kind)
 {
     return kind == JK_CT || kind == JK_CT_13 ? (u32)(CT_THREADS * CT_EPT) : kind == JK_CT_HALF ? (u32)(CTH_THREADS * CT_EPT) :
            kind == JK_CT_WIDE ? (u32)(CT_THREADS * CT_EPT_WIDE) : kind == JK_CT_HALF_WIDE ? (u32)(CTH_THREADS * CT_EPT_WIDE) :
-           kind == JK_CT_MID ? (u32)(CT_THREADS * CTM_EPT) : kind == JK_CT_HALF_MID || kind == JK_CT_HALF_MID_G || kind == JK_CT_G13 ? (u32)(CTH_THREADS * CTM_EPT) : 0u;
+           kind == JK_CT_MID ? (u32)(CT_THREADS * CTM_EPT) : kind == JK_CT_HALF_MID || kind == JK_CT_HALF_MID_G || kind == JK_CT_G13 ? (u32)(CTH_THREADS * CTM_EPT) :
+           kind == JK_CT_Q12 ? (u32)(CTH_THREADS * CTQ_EPT) : 0u;
 }
 u32 join_table_tuples(int kind)
 {
     return kind == JK_CT ? (u32)CT_CHUNK : kind == JK_CT_13 || kind == JK_CT_WIDE ? (u32)CT13_CHUNK : kind == JK_CT_HALF ? (u32)CTH_CHUNK : kind == JK_CT_HALF_WIDE ? (u32)CTHW_CHUNK :
-           kind == JK_CT_MID ? (u32)CTM_CHUNK : kind == JK_CT_HALF_MID || kind == JK_CT_HALF_MID_G || kind == JK_CT_G13 ? (u32)CTHM_CHUNK : kind == JK_BKT_BIG ? (u32)BJ2_CHUNK : (u32)BJ_CHUNK;
+           kind == JK_CT_MID ? (u32)CTM_CHUNK : kind == JK_CT_HALF_MID || kind == JK_CT_HALF_MID_G || kind == JK_CT_G13 ? (u32)CTHM_CHUNK : kind == JK_CT_Q12 ? (u32)CTQ_CHUNK :
+           kind == JK_BKT_BIG ? (u32)BJ2_CHUNK : (u32)BJ_CHUNK;
 }
-int join_ct_min_radix_bits(int kind) { return kind == JK_CT_G13 ? CT13_MIN_RADIX_BITS : CT_MIN_RADIX_BITS; }
+int join_ct_min_radix_bits(int kind) { return kind == JK_CT_G13 ? CT13_MIN_RADIX_BITS : kind == JK_CT_Q12 ? CTQ_KB : CT_MIN_RADIX_BITS; }
 
 static size_t bj_lds_bytes(int threads, int chunk, int bbits)
 {
@@ -2588,6 +2593,8 @@ static void allow_big_lds()
     SET_LDS((k_join_ct<CTH_THREADS, CTHM_CHUNK, CTHM_BUCKET_BITS, CTM_EPT, false, true, true>), ct_lds_bytes(CTH_THREADS, CTHM_CHUNK, CTHM_BUCKET_BITS));
     SET_LDS((k_join_ct<CTH_THREADS, CTHM_CHUNK, CTHM_BUCKET_BITS, CTM_EPT, false, false, true>), ct_lds_bytes(CTH_THREADS, CTHM_CHUNK, CTHM_BUCKET_BITS));
     SET_LDS((k_join_ct<CTH_THREADS, CTHM_CHUNK, CTHM_BUCKET_BITS, CTM_EPT, false, true, true, CT13_KB>), ct_lds_bytes(CTH_THREADS, CTHM_CHUNK, CTHM_BUCKET_BITS));
+    SET_LDS((k_join_ct<CTH_THREADS, CTQ_CHUNK, CTQ_BUCKET_BITS, CTQ_EPT, false, true, true, CTQ_KB>), ct_lds_bytes(CTH_THREADS, CTQ_CHUNK, CTQ_BUCKET_BITS));
+    SET_LDS((k_join_ct<CTH_THREADS, CTQ_CHUNK, CTQ_BUCKET_BITS, CTQ_EPT, false, false, true, CTQ_KB>), ct_lds_bytes(CTH_THREADS, CTQ_CHUNK, CTQ_BUCKET_BITS));
     SET_LDS((k_join_ct<CTH_THREADS, CTHM_CHUNK, CTHM_BUCKET_BITS, CTM_EPT, false, false, true, CT13_KB>), ct_lds_bytes(CTH_THREADS, CTHM_CHUNK, CTHM_BUCKET_BITS));
     SET_LDS((k_join_ct<CTH_THREADS, CTHW_CHUNK, CTHW_BUCKET_BITS, CT_EPT_WIDE, false, true>), ct_lds_bytes(CTH_THREADS, CTHW_CHUNK, CTHW_BUCKET_BITS));
     SET_LDS((k_join_bkt<BJ_THREADS, BJ_CHUNK, BJ_BUCKET_BITS, BJ_EPT, false, true, true>), bj_lds_bytes(BJ_THREADS, BJ_CHUNK, BJ_BUCKET_BITS));
@@ -2967,6 +2974,10 @@ void launch_join(hipStream_t st, const void *d_R, const u64 *d_startR, const voi
         else if (kind == JK_CT_13) LAUNCH_CT_N(CT_THREADS, CT13_CHUNK, CT13_BUCKET_BITS, CT_EPT);
         else if (kind == JK_CT_MID) LAUNCH_CT_N(CT_THREADS, CTM_CHUNK, CTM_BUCKET_BITS, CTM_EPT);
         else if (kind == JK_CT_HALF_MID) LAUNCH_CT_N(CTH_THREADS, CTHM_CHUNK, CTHM_BUCKET_BITS, CTM_EPT);
+        else if (kind == JK_CT_Q12)
+            hipLaunchKernelGGL((k_join_ct<CTH_THREADS, CTQ_CHUNK, CTQ_BUCKET_BITS, CTQ_EPT, false, true, true, CTQ_KB>), dim3(grid), dim3(CTH_THREADS),
+                               ct_lds_bytes(CTH_THREADS, CTQ_CHUNK, CTQ_BUCKET_BITS), st, nR, nS, d_tasks, d_ntasks, radix_bits, o, out_capacity,
+                               d_out_count, (u64 *)nullptr, 0u, d_skip);
         else if (kind == JK_CT_G13)
             hipLaunchKernelGGL((k_join_ct<CTH_THREADS, CTHM_CHUNK, CTHM_BUCKET_BITS, CTM_EPT, false, true, true, CT13_KB>), dim3(grid), dim3(CTH_THREADS),
                                ct_lds_bytes(CTH_THREADS, CTHM_CHUNK, CTHM_BUCKET_BITS), st, nR, nS, d_tasks, d_ntasks, radix_bits, o, out_capacity,
@@ -2995,6 +3006,12 @@ void launch_join(hipStream_t st, const void *d_R, const u64 *d_startR, const voi
     if (kind == JK_CT_HALF_MID) {
         hipLaunchKernelGGL((k_join_ct<CTH_THREADS, CTHM_CHUNK, CTHM_BUCKET_BITS, CTM_EPT, false, false>), dim3(grid), dim3(CTH_THREADS),
                            ct_lds_bytes(CTH_THREADS, CTHM_CHUNK, CTHM_BUCKET_BITS), st, vR, vS, d_tasks,
+                           d_ntasks, radix_bits, (Pair *)d_out, out_capacity, d_out_count, (u64 *)nullptr, 0u, (const u32 *)nullptr);
+        return;
+    }
+    if (kind == JK_CT_Q12) {
+        hipLaunchKernelGGL((k_join_ct<CTH_THREADS, CTQ_CHUNK, CTQ_BUCKET_BITS, CTQ_EPT, false, false, true, CTQ_KB>), dim3(grid), dim3(CTH_THREADS),
+                           ct_lds_bytes(CTH_THREADS, CTQ_CHUNK, CTQ_BUCKET_BITS), st, vR, vS, d_tasks,
                            d_ntasks, radix_bits, (Pair *)d_out, out_capacity, d_out_count, (u64 *)nullptr, 0u, (const u32 *)nullptr);
         return;
     }

@@ -152,7 +152,7 @@ struct FPair { u64 r, s; };
 bool fused_two_pass_ok(int b1, int b2) { return b1 >= 1 && b2 >= 1 && b1 <= 9 && b2 <= 9 && b1 + b2 <= 16; }
 u32 join_probe_split(int kind) { return jk_is_ct(kind) ? 16384u : 0u; }
 u32 join_table_tuples(int kind) { return jk_is_ct(kind) ? 16352u : kind == JK_BKT_BIG ? 8448u : (u32)BJ_CHUNK; }
-int join_ct_min_radix_bits(int kind) { return kind == JK_CT_G13 ? 13 : 16; }
+int join_ct_min_radix_bits(int kind) { return kind == JK_CT_G13 ? 13 : kind == JK_CT_Q12 ? 12 : 16; }
 int seg_max() { return 16; }
 int tag_bits() { return 4; }
 bool narrow_pass_ok(int bits) { return bits >= 1 && bits <= 8; }

@@ -2,7 +2,7 @@
 """tests/fuzz_gpu.py -- randomized differential test of the HIP path against the CPU oracle (run by hand on the GPU box).
 Random sizes (incl. tile/unit/table boundaries), value domains, duplicate structure, skew, radix plans and
 probe splits; compares (count, checksum) and, for small outputs, the sorted pair sets.  python tests/fuzz_gpu.py [seconds] [seed]
-RHJ_FUZZ_BIG=1..10 forces the oversized-partition kernels (1: chunked 16-byte entries, 2 / 3: compact table at full / half
+RHJ_FUZZ_BIG=1..11 forces the oversized-partition kernels (1: chunked 16-byte entries, 2 / 3: compact table at full / half
 size where the plan allows, 4 / 5 with 20 probe slots, 6 / 7 the 12288- / 6144-entry geometries); with RHJ_FUZZ_NARROW=1 half of
 the cases run a 16-, 17- or 18-bit plan that stores its partitions in the narrow {payload, rowID} format (rowIDs start at 10^7 on S; every 16th case has one rowID >= 2^32, which must
 send the join back to 16-byte tuples)."""

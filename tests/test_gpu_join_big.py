@@ -377,22 +377,27 @@ def test_a_huge_probe_split_from_the_caller(engine, oracle, plan):
     assert len(got) == len(exp) and np.array_equal(sorted_pairs(got), sorted_pairs(exp))
 
 
+CT_Q12 = 11
+
+
 @pytest.mark.parametrize("narrow", [0, 2])
-@pytest.mark.parametrize("plan", [Opts(2, 7, 6), Opts(2, 7, 7), Opts(2, 8, 7), Opts(2, 8, 8)])
-def test_13_bit_index_compact_table_under_13_to_16_bit_plans(oracle, plan, narrow):
-    """k_join_ct<.., KB = 13>: table entries {key of up to 51 bits | 13-bit arrival index}, what plans of 13-15 radix bits take for
-    partitions of 2-5 K tuples since round 4.  Forced here onto few, large partitions (chunks of the 6144-entry table, several
-    probe tasks per partition), duplicates on both sides, long buckets, unmatched probes; and chosen BY ITSELF for a 7+7-bit join
-    whose partitions average 2.4 K tuples."""
+@pytest.mark.parametrize("kind,plan", [(CT_G13, Opts(2, 7, 6)), (CT_G13, Opts(2, 7, 7)), (CT_G13, Opts(2, 8, 7)), (CT_G13, Opts(2, 8, 8)),
+                                       (CT_Q12, Opts(2, 6, 6)), (CT_Q12, Opts(2, 7, 6)), (CT_Q12, Opts(2, 8, 8))])
+def test_narrow_index_compact_tables_under_12_to_16_bit_plans(oracle, kind, plan, narrow):
+    """k_join_ct<.., KB = 13> (6144 entries {key of up to 51 bits | 13-bit arrival index}: what plans of 13-15 radix bits take for
+    partitions of 2-5 K tuples since round 4) and <.., KB = 12> (4096 entries, keys of up to 52 bits: plans of 12 bits).  Forced
+    here onto few, large partitions (chunks of the table, several probe tasks per partition), exactly one table and one beyond,
+    duplicates on both sides, unmatched probes; and chosen BY ITSELF for a 7+7-bit join whose partitions average 2.4 K tuples and
+    a 6+6-bit join of 3 K-tuple partitions."""
     tb = plan.bits1 + plan.bits2
+    table = 6_144 if kind == CT_G13 else 4_096
     e = Engine(0)
     try:
         e.set_option("join.big_tables", 1)
-        e.set_option("join.big_kernel", CT_G13)
+        e.set_option("join.big_kernel", kind)
         e.set_option("partition.narrow", narrow)
-        e.narrow = narrow
-        rng = np.random.default_rng(tb * 10 + narrow)
-        for nR, nS, nlow, dup in ((30_000, 50_000, 3, 1), (6_144, 6_144, 1, 1), (6_145, 6_150, 1, 1), (40_000, 25_000, 5, 4), (2_500, 9_000, 2, 1)):
+        rng = np.random.default_rng(tb * 10 + narrow + kind)
+        for nR, nS, nlow, dup in ((30_000, 50_000, 3, 1), (table, table, 1, 1), (table + 1, table + 6, 1, 1), (40_000, 25_000, 5, 4), (2_500, 9_000, 2, 1)):
             vals = rng.permutation(1 << 22)[:max(nR // dup, 1)].astype(np.uint64)
             rv = vals[rng.integers(0, len(vals), nR)] if dup > 1 else vals[:nR]
             lows = np.random.default_rng(nlow).permutation(1 << tb)[:nlow].astype(np.uint64)
@@ -404,12 +409,13 @@ def test_13_bit_index_compact_table_under_13_to_16_bit_plans(oracle, plan, narro
             got = e.join(R, S, opts=plan)
             exp = oracle.join(R, S)
             assert len(got) == len(exp) and np.array_equal(sorted_pairs(got), sorted_pairs(exp))
-            assert e.info("last.join_kernel") == CT_G13
-        if (plan.bits1, plan.bits2) == (7, 7):                               # the automatic choice: 40M tuples, 2.4 K per partition
+            assert e.info("last.join_kernel") == kind
+        auto = {(7, 7): 40_000_000, (6, 6): 12_000_000}.get((plan.bits1, plan.bits2))
+        if auto and ((kind == CT_G13) == (tb == 14)):                        # the automatic choice at these sizes
             e.set_option("join.big_tables", -1)
             e.set_option("join.big_kernel", -1)
             e.set_option("partition.narrow", -1)
-            n = 40_000_000
+            n = auto
             dR, dS, dO = e.alloc(16 * n), e.alloc(16 * n), e.alloc(16 * n)
             e.generate(GEN_R, dR, n, 0, n)
             e.generate(GEN_S_UNIFORM, dS, n, 0, n, seed=5)
@@ -417,6 +423,6 @@ def test_13_bit_index_compact_table_under_13_to_16_bit_plans(oracle, plan, narro
             assert e.join_dev(dR, n, dS, n, dO, n) == exp_n
             assert e.pairs_checksum(dO, n) == exp_c
             t = e.timings()
-            assert (t["passes"], t["bits1"] + t["bits2"]) == (2, 14) and e.info("last.join_kernel") == CT_G13
+            assert (t["passes"], t["bits1"] + t["bits2"]) == (2, tb) and e.info("last.join_kernel") == kind
     finally:
         e.close()

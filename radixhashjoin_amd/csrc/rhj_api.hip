@@ -192,7 +192,8 @@ struct rhj_ctx {
     DevBuf b_in[2], b_out[2], b_cnt[2];   // device: staged blob, pair buffers, per-join {count, ticket}
     hipEvent_t b_ev[2] = {nullptr, nullptr};
     DevBuf fuse_ctl;                   // one-pass joins in three launches: global histograms, digit cursors, tickets (k_hist_fused2)
-    bool fuse_clean = false;           // ... which the kernels leave zeroed (false: the next call clears them first)
+    bool fuse_clean = false;           // ... whose copy for the next call the kernels leave zeroed (false: the next call clears both first)
+    int fuse_parity = 0;               // the copy the next call uses
     u64 *h_pub = nullptr, *h_pub_dev = nullptr;   // pinned: the join counters as the bucket join's last workgroup publishes them
     int opt_fused = -1;                // -1: automatic (RHJ_FUSE env, default 1), 0 / 1
     std::vector<u64> shard_ps_host[2]; // the class boundaries of the last rhj_shard_stats of each side (host copy)
@@ -1163,8 +1164,13 @@ int join_one_pass_fused(rhj_ctx *ctx, const void *d_R, u64 nR, const void *d_S, 
     RHJCHK(ensure(ctx, ctx->part_S, (size_t)nS * 16));
     void *out[2] = {ctx->part_R.p, ctx->part_S.p};
     u64 *ps[2] = {(u64 *)ctx->ps_R.p, (u64 *)ctx->ps_S.p};
+    // units: the scatter's workgroups of R and S together fill the chip ONCE (9 bits: one 1024-thread workgroup per CU, below two
+    // of 512 threads) -- every workgroup of k_scatter_fused2 first derives the partition starts and reserves its ranges with
+    // 2^bits atomics, so a second round of workgroups pays that again ([measured] 3 * 10^6 x 3 * 10^6, 9 bits, units per
+    // relation 733 / 256 / 128: scatter 85 / 54 / 44 us, the join 0.191 / 0.157 / 0.148 ms)
+    const u64 target_units = bits >= 9 ? 128 : 256;
     for (int i = 0; i < 2; i++) {
-        const PassGeom g = make_geom(n[i], 1, 0, bits);
+        const PassGeom g = make_geom(n[i], 1, 0, bits, target_units);
         RHJCHK(ensure(ctx, *uh[i], (size_t)g.max_units * nbins * 4));
         h.side[i] = PassSide{in[i], out[i], nullptr, nullptr, (u32 *)uh[i]->p, nullptr, ps[i], nullptr, g};
     }
@@ -1187,14 +1193,12 @@ int join_one_pass_fused(rhj_ctx *ctx, const void *d_R, u64 nR, const void *d_S, 
     }
     ctx->fuse_clean = false;                                 // until this call has run to its end
     u64 *d_count = (u64 *)ctx->counters.p;
-    {
-        Span s(ctx, RHJ_K_HIST);
-        launch_fused_pass(ctx->stream, h, bits, 0, ctx->fuse_ctl.p, probe_split, max_tasks, join_table_tuples(kind), (JoinTask *)ctx->tasks.p,
-                          d_count);
-    }
-    {
-        Span s(ctx, RHJ_K_SCATTER);
-        launch_fused_pass(ctx->stream, h, bits, 1, ctx->fuse_ctl.p, 0, 0, 0, nullptr, nullptr);
+    const int parity = ctx->fuse_parity;
+    ctx->fuse_parity ^= 1;
+    for (int phase = 0; phase < 2; phase++) {
+        Span s(ctx, phase == 0 ? RHJ_K_HIST : RHJ_K_SCATTER);
+        launch_fused_pass(ctx->stream, h, bits, phase, parity, ctx->fuse_ctl.p, probe_split, max_tasks, join_table_tuples(kind),
+                          (JoinTask *)ctx->tasks.p, d_count);
     }
     ctx->cur_R = ctx->part_R.p;
     ctx->cur_S = ctx->part_S.p;

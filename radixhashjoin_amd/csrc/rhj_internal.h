@@ -119,10 +119,11 @@ struct PassSide {
 };
 struct PassPairHost { PassSide side[2]; u64 *zero8 = nullptr; /* eight 64-bit words cleared by the first launch, or null */ int mix = 0; };
 void launch_pass_pair(hipStream_t st, const PassPairHost &h, int shift, int bits, int phase);
-// one-pass joins in three launches (see k_hist_fused2): phase 0 histogram + boundaries + task list, phase 1 scatter
+// one-pass joins in three launches (see k_hist_fused2): phase 0 histograms, phase 1 scatter + boundaries + task list (same
+// arguments to both); parity: which of the two copies of the control block this call uses (the caller alternates)
 size_t fuse_ctl_bytes();
 u32 *fuse_join_ticket(void *d_ctl);
-void launch_fused_pass(hipStream_t st, const PassPairHost &h, int bits, int phase, void *d_ctl, u32 probe_split, u32 max_tasks,
+void launch_fused_pass(hipStream_t st, const PassPairHost &h, int bits, int phase, int parity, void *d_ctl, u32 probe_split, u32 max_tasks,
                        u32 table_tuples, JoinTask *d_tasks, u64 *d_counters);
 constexpr int PASS_PAIR_MAX_BITS = 9;            // the write-combining scatter's range
 bool fused_two_pass_ok(int b1, int b2);

@@ -749,11 +749,13 @@ dev_scatter_wc(const Tup *__restrict__ in, Tup *__restrict__ out, const u64 *__r
                const u32 *__restrict__ unit_start, u32 nseg, u64 L, int shift, int bits,
                const u64 *__restrict__ unit_base, const u64 *__restrict__ unit_rng, u32 n_rng_units, const u32 u,
                const u64 *__restrict__ inP = nullptr, const u32 *__restrict__ inK = nullptr, u64 key_add = 0, int mix = 0,
-               const u32 *__restrict__ hist_rows = nullptr, u64 *__restrict__ cursor = nullptr, u64 n_single = 0)
+               const u32 *__restrict__ hist_rows = nullptr, u64 *__restrict__ cursor = nullptr, u64 n_single = 0,
+               const u32 *pbase = nullptr)
 {
     // cursor (one-pass joins, k_scatter_fused2): no unit_base table and no scan -- the unit reserves its range of every digit
-    // with ONE atomicAdd of its histogram row (hist_rows, from k_hist_fused2) on the digit's cursor, which the histogram launch's
-    // last workgroup left at the partition's start.  Units then lie in a partition in arrival order: unspecified, like the
+    // with ONE atomicAdd of its histogram row (hist_rows, from k_hist_fused2) on the digit's cursor, which starts every call at
+    // zero: the range begins pbase[digit] (LDS: the partition's start, which the workgroup has just derived from the global
+    // histogram) + what the atomicAdd returned.  Units then lie in a partition in arrival order: unspecified, like the
     // order inside a partition has always been.  The unit is rows [u * L, (u + 1) * L) of the n_single tuples.
     // mix (16-byte input only, see MIX_* in rhj_internal.h): MIX_STORE -- first pass inside a join: the payload becomes
     // mix64(payload) as it is loaded, and that is what is written; MIX_DIGIT -- the digit comes from mix64(payload), the tuple
@@ -792,9 +794,23 @@ dev_scatter_wc(const Tup *__restrict__ in, Tup *__restrict__ out, const u64 *__r
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     auto dig = [&](u64 p) -> u32 { return (u32)((mix == MIX_DIGIT ? mix64(p) : p) >> shift) & mask; };
 
+    // (the first tile is requested BEFORE the cursors are fetched: with cursors reserved by device-scope atomics -- one-pass joins --
+    // the two round trips would otherwise follow each other in a workgroup that has one tile to move)
+    Tup ta[WC_TPT], tb_[WC_TPT];
+    auto load_first = [&](Tup (&t)[WC_TPT]) {
+        if (beg >= end) return;
+        const u32 last = ((end - beg < (u64)TILE) ? (u32)(end - beg) : (u32)TILE) - 1u;
+#pragma unroll
+        for (int k = 0; k < WC_TPT; k++) {
+            const u32 i = k * THREADS + tid;
+            if constexpr (IN_NARROW) { const u64 j = beg + (i < last ? i : last); t[k].payload = inP[j]; t[k].key = key_add + inK[j]; }
+            else t[k] = in[beg + (i < last ? i : last)];
+        }
+    };
+    load_first(ta);
     for (u32 b = tid; b < nbins; b += THREADS) {
-        const u64 g = cursor != nullptr ? atomicAdd((unsigned long long *)&cursor[(size_t)b * FUSE_STRIDE64_FWD],
-                                                    (unsigned long long)hist_rows[(u64)u * nbins + b])
+        const u64 g = cursor != nullptr ? pbase[b] + atomicAdd((unsigned long long *)&cursor[(size_t)b * FUSE_STRIDE64_FWD],
+                                                               (unsigned long long)hist_rows[(u64)u * nbins + b])
                                         : unit_base[(u64)u * nbins + b];
         gnext[b] = g;
         LO[b] = (u32)g & 7u;
@@ -905,9 +921,7 @@ dev_scatter_wc(const Tup *__restrict__ in, Tup *__restrict__ out, const u64 *__r
         }
     };
 
-    Tup ta[WC_TPT], tb_[WC_TPT];
     u64 cur = beg;
-    if (cur < end) load_tile(ta, cur);
     while (cur < end) {
         // the prefetch is issued on every path (past the unit's end: the current tile again, unused), so that the wait for
         // the current tile is "all but the 4 loads just issued" instead of vmcnt(0)
@@ -965,16 +979,22 @@ __global__ void __launch_bounds__(THREADS) k_scatter_wc2(PassPair a, int shift, 
 // ---- one-pass joins in THREE launches (mid-size joins are launch-bound: 10^6 x 10^6 was 8 dependent launches for 77 us of
 // kernel time) ------------------------------------------------------------------------------------------------------------
 //   k_hist_fused2     per-unit histograms of R and S (grid.y = relation; unit ranges computed, no unit tables), each row also
-//                     added to the relation's global histogram; the LAST workgroup to finish (ticket) turns the two global
-//                     histograms into partition boundaries and digit cursors, clears the join counters and writes the JOIN
-//                     TASK LIST (what k_init_single_segment2, three scan launches, k_make_tasks and a memset did)
-//   k_scatter_fused2  the write-combining scatter; a unit reserves its output ranges with one atomicAdd per digit (cursor)
+//                     added to the relation's global histogram (fire-and-forget atomics; the launch boundary orders them)
+//   k_scatter_fused2  the write-combining scatter.  EVERY workgroup turns its relation's global histogram into partition starts
+//                     itself (nbins x FUSE_COPIES loads that hit L2 and one workgroup scan: ~2 us, side by side in all
+//                     workgroups -- a "last workgroup" doing it once at the end of the histogram launch was ~10 us of one
+//                     workgroup with the chip idle), and reserves its output ranges with one atomicAdd per digit on a cursor
+//                     that counts from zero.  Workgroup (0, 0) moves no tuples: it is the PLANNER -- both relations'
+//                     boundaries to HBM for the join, the JOIN TASK LIST and its counters (what k_init_single_segment2, three
+//                     scan launches, k_make_tasks and a memset did), while the others scatter.
 //   k_join_bkt        as before; its last workgroup publishes the counters to pinned host memory (no D2H copy)
-// FuseCtl lives in HBM, zero between calls: the last workgroup leaves it so (a failed call makes the host clear it).
+// FuseCtl lives in HBM in TWO copies used by alternate calls: the histogram launch of a call zeroes the copy of the NEXT call
+// (plain stores, nobody else touches it), so no launch ever waits for a clean-up (a failed call makes the host clear both).
 struct FuseCtl {
-    u32 *ghist;          // [2][512] global digit histograms of R, S
-    u64 *cursor;         // [2][512] next free slot per digit
-    u32 *ticket;         // [0]: workgroups of k_hist_fused2 that have finished
+    u32 *ghist;          // [2][FUSE_COPIES][512] global digit histograms of R, S (this call's copy)
+    u64 *cursor;         // [2][512] tuples of the digit already placed
+    u32 *ghist_next;     // the next call's copy, zeroed by this call's k_hist_fused2
+    u64 *cursor_next;
 };
 struct FuseTasks { u32 probe_split, max_tasks, table_tuples, units_per_wg; JoinTask *tasks; u64 *counters; };
 // Every counter on its own 128-byte line, the global histograms in FUSE_COPIES copies (unit u adds to copy u mod FUSE_COPIES):
@@ -988,86 +1008,103 @@ k_hist_fused2(PassPair a, int shift, int bits, FuseCtl fc, FuseTasks ft)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     u32 *cnt = reinterpret_cast<u32 *>(smem);                      // nbins
-    __shared__ u64 st[2][FUSE_MAX_BINS + 1];                       // last workgroup: partition boundaries of R, S
-    __shared__ u32 wsum[PART_THREADS / 64];
-    __shared__ u64 wmax[2][PART_THREADS / 64];
-    __shared__ u32 is_last;
     const PassRel &x = a.r[blockIdx.y];
     const u32 nbins = 1u << bits, mask = nbins - 1;
     const int tid = threadIdx.x;
+    {   // the NEXT call's control block, and this call's join counters (k_scatter_fused2's planner and the join write them later)
+        const u32 gthreads = gridDim.x * gridDim.y * PART_THREADS, gid = (blockIdx.y * gridDim.x + blockIdx.x) * PART_THREADS + tid;
+        for (u32 i = gid; i < 2u * FUSE_COPIES * FUSE_MAX_BINS; i += gthreads) fc.ghist_next[(size_t)i * FUSE_STRIDE32] = 0;
+        for (u32 i = gid; i < 2u * FUSE_MAX_BINS; i += gthreads) fc.cursor_next[(size_t)i * FUSE_STRIDE64] = 0;
+        if (gid < 8) ft.counters[gid] = 0;
+    }
     // a workgroup counts ft.units_per_wg consecutive units (a row each, for the scatter) and adds their SUM to the global
     // histogram once: device-scope atomics are the scarce thing here ([measured] ~7 per ns over the whole chip)
     u32 *wtot_ = cnt + nbins;                                        // this workgroup's sum over its units
     auto dig = [&](u64 p) -> u32 { return (u32)((a.mix ? mix64(p) : p) >> shift) & mask; };
     const u32 u0 = blockIdx.x * ft.units_per_wg;
-    if ((u64)u0 * x.L < x.n) {
-        for (u32 b = tid; b < nbins; b += PART_THREADS) wtot_[b] = 0;
-        for (u32 u = u0; u < u0 + ft.units_per_wg && (u64)u * x.L < x.n; u++) {
-            const u64 beg = (u64)u * x.L, end = (beg + x.L < x.n) ? beg + x.L : x.n;
-            for (u32 b = tid; b < nbins; b += PART_THREADS) cnt[b] = 0;
-            __syncthreads();
-            u64 i = beg + tid;
-            for (; i + 3ull * PART_THREADS < end; i += 4ull * PART_THREADS) {
-                const Tup t0 = x.in[i], t1 = x.in[i + PART_THREADS], t2 = x.in[i + 2 * PART_THREADS], t3 = x.in[i + 3 * PART_THREADS];
-                atomicAdd(&cnt[dig(t0.payload)], 1u);
-                atomicAdd(&cnt[dig(t1.payload)], 1u);
-                atomicAdd(&cnt[dig(t2.payload)], 1u);
-                atomicAdd(&cnt[dig(t3.payload)], 1u);
-            }
-            for (; i < end; i += PART_THREADS) atomicAdd(&cnt[dig(x.in[i].payload)], 1u);
-            __syncthreads();
-            u32 *row = x.unit_hist + (u64)u * nbins;
-            for (u32 b = tid; b < nbins; b += PART_THREADS) {       // (thread tid owns bins tid, tid + 512: no barrier needed for wtot_)
-                const u32 c = cnt[b];
-                row[b] = c;
-                wtot_[b] += c;
-            }
-            __syncthreads();
+    if ((u64)u0 * x.L >= x.n) return;
+    for (u32 b = tid; b < nbins; b += PART_THREADS) wtot_[b] = 0;
+    for (u32 u = u0; u < u0 + ft.units_per_wg && (u64)u * x.L < x.n; u++) {
+        const u64 beg = (u64)u * x.L, end = (beg + x.L < x.n) ? beg + x.L : x.n;
+        for (u32 b = tid; b < nbins; b += PART_THREADS) cnt[b] = 0;
+        __syncthreads();
+        u64 i = beg + tid;
+        for (; i + 3ull * PART_THREADS < end; i += 4ull * PART_THREADS) {
+            const Tup t0 = x.in[i], t1 = x.in[i + PART_THREADS], t2 = x.in[i + 2 * PART_THREADS], t3 = x.in[i + 3 * PART_THREADS];
+            atomicAdd(&cnt[dig(t0.payload)], 1u);
+            atomicAdd(&cnt[dig(t1.payload)], 1u);
+            atomicAdd(&cnt[dig(t2.payload)], 1u);
+            atomicAdd(&cnt[dig(t3.payload)], 1u);
         }
-        u32 *gh = fc.ghist + (size_t)(blockIdx.y * FUSE_COPIES + (blockIdx.x & (FUSE_COPIES - 1))) * FUSE_MAX_BINS * FUSE_STRIDE32;
-        u32 seen = 0;
-        for (u32 b = tid; b < nbins; b += PART_THREADS) {
-            const u32 c = wtot_[b];
-            if (c) seen += __hip_atomic_fetch_add(&gh[(size_t)b * FUSE_STRIDE32], c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        for (; i < end; i += PART_THREADS) atomicAdd(&cnt[dig(x.in[i].payload)], 1u);
+        __syncthreads();
+        u32 *row = x.unit_hist + (u64)u * nbins;
+        for (u32 b = tid; b < nbins; b += PART_THREADS) {       // (thread tid owns bins tid, tid + 512: no barrier needed for wtot_)
+            const u32 c = cnt[b];
+            row[b] = c;
+            wtot_[b] += c;
         }
-        if (seen == 0xFFFFFFFFu) cnt[0] = seen;                     // (never true: keeps the atomics' return values alive)
+        __syncthreads();
     }
-    // ---- ticket: the last workgroup of the launch (either relation) finishes the partition phase ---------------------
-    // No fence: the global-histogram atomics above RETURN (their values are consumed below), so they have been performed at
-    // device scope when the ticket is taken, and the last workgroup reads the histograms with device-scope atomic loads.  (A
-    // release fence here is an L2 write-back per workgroup on this multi-XCD part; the rows written above are for the NEXT
-    // launch.)
-    __syncthreads();
-    if (tid == 0) is_last = __hip_atomic_fetch_add(fc.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x * gridDim.y - 1 ? 1u : 0u;
-    __syncthreads();
-    if (!is_last) return;
-    for (int rel = 0; rel < 2; rel++) {
-        const PassRel &y = a.r[rel];
+    u32 *gh = fc.ghist + (size_t)(blockIdx.y * FUSE_COPIES + (blockIdx.x & (FUSE_COPIES - 1))) * FUSE_MAX_BINS * FUSE_STRIDE32;
+    for (u32 b = tid; b < nbins; b += PART_THREADS) {
+        const u32 c = wtot_[b];
+        if (c) (void)__hip_atomic_fetch_add(&gh[(size_t)b * FUSE_STRIDE32], c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
+
+// grid (1 + units, 2): workgroup (0, 0) plans the join, (0, 1) has nothing to do, (1 + u, rel) scatters unit u of relation rel
+template <int THREADS>
+__global__ void __launch_bounds__(THREADS) k_scatter_fused2(PassPair a, int shift, int bits, FuseCtl fc, FuseTasks ft)
+{
+    static_assert(THREADS >= FUSE_MAX_BINS || THREADS == WC_THREADS_SMALL, "one digit per thread");
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    __shared__ u32 pbase[FUSE_MAX_BINS];
+    __shared__ u32 wsum[THREADS / 64];
+    __shared__ u64 wmax[2][THREADS / 64];
+    const u32 nbins = 1u << bits;                                   // <= THREADS (8 bits at most with 512 threads: wc_threads_for)
+    const int tid = threadIdx.x;
+    auto total_of = [&](int rel) -> u32 {                           // digit tid's tuples in relation rel (the launch boundary made them visible)
         u32 c = 0;
         if ((u32)tid < nbins) {
 #pragma unroll
-            for (int cp = 0; cp < FUSE_COPIES; cp++) {
-                u32 *g = fc.ghist + ((size_t)(rel * FUSE_COPIES + cp) * FUSE_MAX_BINS + tid) * FUSE_STRIDE32;
-                c += __hip_atomic_load(g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                __hip_atomic_store(g, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);       // left clean for the next call
-            }
+            for (int cp = 0; cp < FUSE_COPIES; cp++) c += fc.ghist[((size_t)(rel * FUSE_COPIES + cp) * FUSE_MAX_BINS + tid) * FUSE_STRIDE32];
         }
+        return c;
+    };
+    if (blockIdx.x != 0) {
+        const PassRel &x = a.r[blockIdx.y];
+        const u32 u = blockIdx.x - 1;
+        if ((u64)u * x.L >= x.n) return;
         u32 tot;
-        const u32 ex = block_excl_scan<PART_THREADS>(c, wsum, tot);
-        if ((u32)tid < nbins) {
-            st[rel][tid] = ex;
-            y.part_start[tid] = ex;
-            fc.cursor[((size_t)rel * FUSE_MAX_BINS + tid) * FUSE_STRIDE64] = ex;
-        }
-        if (tid == 0) { st[rel][nbins] = y.n; y.part_start[nbins] = y.n; }
+        const u32 ex = block_excl_scan<THREADS>(total_of((int)blockIdx.y), wsum, tot);
+        if ((u32)tid < nbins) pbase[tid] = ex;                      // (read back by the same thread: digit b = tid)
+        dev_scatter_wc<THREADS>(x.in, x.out, nullptr, nullptr, 1u, x.L, shift, bits, nullptr, (const u64 *)nullptr, 0u, u, nullptr, nullptr, 0,
+                                a.mix, x.unit_hist, fc.cursor + (size_t)blockIdx.y * FUSE_MAX_BINS * FUSE_STRIDE64, x.n, pbase);
+        return;
     }
-    if (tid == 0) __hip_atomic_store(fc.ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if (tid < 8) __hip_atomic_store(&ft.counters[tid], (u64)0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // the join counters
+    if (blockIdx.y != 0) return;
+    // ---- the planner: partition boundaries of R and S, then the join task list (k_make_tasks's rules; one workgroup sees
+    // every partition) -------------------------------------------------------------------------------------------------
+    u64 *st0 = reinterpret_cast<u64 *>(smem), *st1 = st0 + FUSE_MAX_BINS + 1;      // (the tile area: this workgroup moves no tuples)
+    {
+        const u32 c0 = total_of(0), c1 = total_of(1);
+        u32 tot;
+        const u32 e0 = block_excl_scan<THREADS>(c0, wsum, tot);
+        const u32 e1 = block_excl_scan<THREADS>(c1, wsum, tot);
+        if ((u32)tid < nbins) {
+            st0[tid] = e0; a.r[0].part_start[tid] = e0;
+            st1[tid] = e1; a.r[1].part_start[tid] = e1;
+        }
+        if (tid == 0) {
+            st0[nbins] = a.r[0].n; a.r[0].part_start[nbins] = a.r[0].n;
+            st1[nbins] = a.r[1].n; a.r[1].part_start[nbins] = a.r[1].n;
+        }
+    }
     __syncthreads();
-    // ---- the join task list (k_make_tasks's rules; one workgroup sees every partition: nbins <= PART_THREADS) ----------
     const u32 k = tid;
     u64 nr = 0, ns = 0, r0 = 0, s0 = 0;
-    if (k < nbins) { r0 = st[0][k]; nr = st[0][k + 1] - r0; s0 = st[1][k]; ns = st[1][k + 1] - s0; }
+    if (k < nbins) { r0 = st0[k]; nr = st0[k + 1] - r0; s0 = st1[k]; ns = st1[k + 1] - s0; }
     u64 mr = nr, ms = ns;
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) {
@@ -1078,7 +1115,7 @@ k_hist_fused2(PassPair a, int shift, int bits, FuseCtl fc, FuseTasks ft)
     if ((tid & 63) == 0) { wmax[0][tid >> 6] = mr; wmax[1][tid >> 6] = ms; }
     __syncthreads();
     u64 maxR = 0, maxS = 0;
-    for (int i = 0; i < PART_THREADS / 64; i++) { maxR = wmax[0][i] > maxR ? wmax[0][i] : maxR; maxS = wmax[1][i] > maxS ? wmax[1][i] : maxS; }
+    for (int i = 0; i < THREADS / 64; i++) { maxR = wmax[0][i] > maxR ? wmax[0][i] : maxR; maxS = wmax[1][i] > maxS ? wmax[1][i] : maxS; }
     u32 nt = 0, bis = 0;
     u64 pbeg = 0, plen = 0, bbeg = 0, blen = 0;
     if (k < nbins && nr != 0 && ns != 0) {
@@ -1092,7 +1129,7 @@ k_hist_fused2(PassPair a, int shift, int bits, FuseCtl fc, FuseTasks ft)
         nt = (u32)((plen + ft.probe_split - 1) / ft.probe_split);
     }
     u32 tot;
-    const u32 ex = block_excl_scan<PART_THREADS>(nt, wsum, tot);
+    const u32 ex = block_excl_scan<THREADS>(nt, wsum, tot);
     u32 slot = ex;
     for (u32 j = 0; j < nt; j++, slot++) {
         if (slot >= ft.max_tasks) break;
@@ -1107,18 +1144,10 @@ k_hist_fused2(PassPair a, int shift, int bits, FuseCtl fc, FuseTasks ft)
         ft.tasks[slot] = t;
     }
     if (tid == 0) {
-        __hip_atomic_store(&ft.counters[1], (u64)(tot < ft.max_tasks ? tot : ft.max_tasks), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ntasks
-        __hip_atomic_store(&ft.counters[2], maxR, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __hip_atomic_store(&ft.counters[3], maxS, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        ft.counters[1] = (u64)(tot < ft.max_tasks ? tot : ft.max_tasks);       // ntasks
+        ft.counters[2] = maxR;
+        ft.counters[3] = maxS;
     }
-}
-
-template <int THREADS>
-__global__ void __launch_bounds__(THREADS) k_scatter_fused2(PassPair a, int shift, int bits, FuseCtl fc)
-{
-    const PassRel &x = a.r[blockIdx.y];
-    dev_scatter_wc<THREADS>(x.in, x.out, nullptr, nullptr, 1u, x.L, shift, bits, nullptr, (const u64 *)nullptr, 0u, blockIdx.x,
-                            nullptr, nullptr, 0, a.mix, x.unit_hist, fc.cursor + (size_t)blockIdx.y * FUSE_MAX_BINS * FUSE_STRIDE64, x.n);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1563,12 +1592,17 @@ __device__ __forceinline__ void bj_publish(const DirectJoin &dj, const u64 *__re
     // the ticket is taken, the last workgroup reads the counters with device-scope atomic loads, and the host reads the pinned
     // block only after the stream has synchronised (the end of a kernel releases at system scope).  (A fence per workgroup is
     // an L2 write-back of the pairs it has just stored: [measured] 35 -> 52 us for the 10^6 x 10^6 join.)
-    if (dj.host_count == nullptr || threadIdx.x != 0) return;
-    if (__hip_atomic_fetch_add(dj.done, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1) {
-        for (int i = 0; i < 7; i++)
-            __hip_atomic_store(&dj.host_count[i], __hip_atomic_load(&counters[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), __ATOMIC_RELAXED,
-                               __HIP_MEMORY_SCOPE_SYSTEM);
-        __hip_atomic_store(dj.done, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    // (the first wavefront: lane 0 takes the ticket, seven lanes copy one counter each -- seven device-scope loads one behind the
+    // other were ~5 us at the end of a 35 us kernel)
+    if (dj.host_count == nullptr || threadIdx.x >= 64) return;
+    u32 ticket = 0;
+    if (threadIdx.x == 0) ticket = __hip_atomic_fetch_add(dj.done, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    ticket = (u32)__builtin_amdgcn_readfirstlane((int)ticket);
+    if (ticket == gridDim.x - 1) {
+        if (threadIdx.x < 7)
+            __hip_atomic_store(&dj.host_count[threadIdx.x], __hip_atomic_load(&counters[threadIdx.x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT),
+                               __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        if (threadIdx.x == 0) __hip_atomic_store(dj.done, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
 }
 
@@ -2716,9 +2750,10 @@ void launch_pass_pair(hipStream_t st, const PassPairHost &h, int shift, int bits
 // between calls (see FuseCtl).  phase 0: histogram + boundaries + task list; phase 1: scatter.
 constexpr size_t FUSE_CURSOR_BYTES = (size_t)2 * FUSE_MAX_BINS * FUSE_STRIDE64 * 8;
 constexpr size_t FUSE_GHIST_BYTES = (size_t)2 * FUSE_COPIES * FUSE_MAX_BINS * FUSE_STRIDE32 * 4;
-size_t fuse_ctl_bytes() { return FUSE_CURSOR_BYTES + FUSE_GHIST_BYTES + 256; }
-u32 *fuse_join_ticket(void *d_ctl) { return (u32 *)((unsigned char *)d_ctl + FUSE_CURSOR_BYTES + FUSE_GHIST_BYTES + 128); }
-void launch_fused_pass(hipStream_t st, const PassPairHost &h, int bits, int phase, void *d_ctl, u32 probe_split, u32 max_tasks,
+constexpr size_t FUSE_COPY_BYTES = FUSE_CURSOR_BYTES + FUSE_GHIST_BYTES;
+size_t fuse_ctl_bytes() { return 2 * FUSE_COPY_BYTES + 256; }
+u32 *fuse_join_ticket(void *d_ctl) { return (u32 *)((unsigned char *)d_ctl + 2 * FUSE_COPY_BYTES + 128); }
+void launch_fused_pass(hipStream_t st, const PassPairHost &h, int bits, int phase, int parity, void *d_ctl, u32 probe_split, u32 max_tasks,
                        u32 table_tuples, JoinTask *d_tasks, u64 *d_counters)
 {
     allow_big_lds();
@@ -2734,26 +2769,31 @@ void launch_fused_pass(hipStream_t st, const PassPairHost &h, int bits, int phas
     }
     if (mu == 0) mu = 1;                                                     // (both relations empty: the ticket logic still runs)
     FuseCtl fc;
-    fc.cursor = (u64 *)d_ctl;
-    fc.ghist = (u32 *)((unsigned char *)d_ctl + FUSE_CURSOR_BYTES);
-    fc.ticket = (u32 *)((unsigned char *)d_ctl + FUSE_CURSOR_BYTES + FUSE_GHIST_BYTES);
+    unsigned char *mine = (unsigned char *)d_ctl + (size_t)(parity & 1) * FUSE_COPY_BYTES, *next = (unsigned char *)d_ctl + (size_t)(~parity & 1) * FUSE_COPY_BYTES;
+    fc.cursor = (u64 *)mine;
+    fc.ghist = (u32 *)(mine + FUSE_CURSOR_BYTES);
+    fc.cursor_next = (u64 *)next;
+    fc.ghist_next = (u32 *)(next + FUSE_CURSOR_BYTES);
+    u32 k = 1;
     if (phase == 0) {
         // units per workgroup: as few global-histogram atomics as a full chip allows (>= ~2 workgroups per CU stay)
         static const u32 forced_k = getenv("RHJ_FUSE_K") ? (u32)atoi(getenv("RHJ_FUSE_K")) : 0u;      // tuning aid
         // ([measured] 10^6 x 10^6, 8 bits: k = 1 / 2 / 4 -> 27 / 24 / 24 us; 4 * 10^6, 9 bits: k = 1 / 2 / 4 / 8 -> 81 / 61 / 55 / 53 us):
         // at most ~32 K atomics per launch while at least 64 workgroups per relation remain, at most 8 units each
-        u32 k = (u32)(((u64)mu * ((u64)2 << bits) + 32767) / 32768);
+        k = (u32)(((u64)mu * ((u64)2 << bits) + 32767) / 32768);
         if (k > mu / 64) k = mu / 64;
         if (k > 8) k = 8;
         if (forced_k) k = forced_k;
         if (k < 1) k = 1;
-        const FuseTasks ft{probe_split, max_tasks, table_tuples, k, d_tasks, d_counters};
+    }
+    const FuseTasks ft{probe_split, max_tasks, table_tuples, k, d_tasks, d_counters};
+    if (phase == 0) {
         hipLaunchKernelGGL(k_hist_fused2, dim3((mu + k - 1) / k, 2), dim3(PART_THREADS), ((size_t)8 << bits), st, a, 0, bits, fc, ft);
-    } else if (wc_threads_for(bits) == WC_THREADS_SMALL) {
-        hipLaunchKernelGGL(k_scatter_fused2<WC_THREADS_SMALL>, dim3(mu, 2), dim3(WC_THREADS_SMALL), wc_lds_bytes(bits, WC_THREADS_SMALL),
-                           st, a, 0, bits, fc);
+    } else if (wc_threads_for(bits) == WC_THREADS_SMALL && bits <= 8) {
+        hipLaunchKernelGGL(k_scatter_fused2<WC_THREADS_SMALL>, dim3(mu + 1, 2), dim3(WC_THREADS_SMALL), wc_lds_bytes(bits, WC_THREADS_SMALL),
+                           st, a, 0, bits, fc, ft);
     } else {
-        hipLaunchKernelGGL(k_scatter_fused2<WC_THREADS>, dim3(mu, 2), dim3(WC_THREADS), wc_lds_bytes(bits, WC_THREADS), st, a, 0, bits, fc);
+        hipLaunchKernelGGL(k_scatter_fused2<WC_THREADS>, dim3(mu + 1, 2), dim3(WC_THREADS), wc_lds_bytes(bits, WC_THREADS), st, a, 0, bits, fc, ft);
     }
 }
 

@@ -1,9 +1,10 @@
 """GPU suite: one-pass joins in three launches (k_hist_fused2 / k_scatter_fused2 / the bucket join publishing its counters to
 pinned host memory; rhj_api.hip join_one_pass_fused).  What the reference does per join with HistogramJob / PartitionJob /
-JoinJob and five barriers (Result.cpp:90-124, structs.cpp:144-204) is here one histogram launch whose last workgroup makes
-the partition boundaries AND the task list, one scatter launch whose units reserve their output ranges with atomics, one
-join launch.  Against the CPU oracle, against the unfused launch sequence ("join.fused" 0), on one context over many calls
-(the control block is left clean by the kernels themselves), count-only, overflow, empty partitions, skew."""
+JoinJob and five barriers (Result.cpp:90-124, structs.cpp:144-204) is here one histogram launch, one scatter launch whose
+workgroups derive the partition boundaries themselves and reserve their output ranges with atomics while a planner workgroup
+writes the task list, one join launch.  Against the CPU oracle, against the unfused launch sequence ("join.fused" 0), on one
+context over many calls (two copies of the control block, each call's histogram launch zeroes the next call's), count-only,
+overflow, empty partitions, skew."""
 import numpy as np
 import pytest
 
@@ -51,8 +52,8 @@ def test_fused_one_pass_equals_oracle_and_unfused(eng, oracle, nR, nS, D, bits):
 
 
 def test_launch_count_and_state_over_many_calls(eng, oracle):
-    """3 launches instead of 8; the control block (global histograms, cursors, tickets) is left clean by the kernels: fifty
-    joins of changing sizes and plans on one context, each checked by count + checksum"""
+    """3 launches instead of 8; the control block (global histograms, cursors) of the next call is zeroed by this call's kernels,
+    whatever the two calls' radix widths: fifty joins of changing sizes and plans on one context, each checked by count + checksum"""
     eng.set_option("join.fused", 1)
     eng.set_profiling(True)
     rng = np.random.default_rng(3)

@@ -1198,8 +1198,10 @@ int join_one_pass_fused(rhj_ctx *ctx, const void *d_R, u64 nR, const void *d_S, 
     for (int phase = 0; phase < 2; phase++) {
         Span s(ctx, phase == 0 ? RHJ_K_HIST : RHJ_K_SCATTER);
         launch_fused_pass(ctx->stream, h, bits, phase, parity, ctx->fuse_ctl.p, probe_split, max_tasks, join_table_tuples(kind),
-                          (JoinTask *)ctx->tasks.p, d_count);
+                          (JoinTask *)ctx->tasks.p, d_count, ctx->h_pub_dev);
     }
+    // the packed result counter (rhj_kernels.hip bj_count_packed) while pairs and workgroups fit its two fields
+    const bool packed = max_tasks < (1u << 16) && (double)nR * (double)nS < 2.8e14;
     ctx->cur_R = ctx->part_R.p;
     ctx->cur_S = ctx->part_S.p;
     ctx->cur_psR = ps[0];
@@ -1212,7 +1214,8 @@ int join_one_pass_fused(rhj_ctx *ctx, const void *d_R, u64 nR, const void *d_S, 
     {
         Span s(ctx, RHJ_K_JOIN);
         launch_join(ctx->stream, ctx->cur_R, ps[0], ctx->cur_S, ps[1], (const JoinTask *)ctx->tasks.p, (const u32 *)(d_count + 1), max_tasks, bits,
-                    d_out, d_out ? cap : 0, d_count, kind, nullptr, nullptr, nullptr, nullptr, ctx->h_pub_dev, fuse_join_ticket(ctx->fuse_ctl.p));
+                    d_out, d_out ? cap : 0, d_count, kind, nullptr, nullptr, nullptr, nullptr, ctx->h_pub_dev,
+                    packed ? nullptr : fuse_join_ticket(ctx->fuse_ctl.p));
     }
     RHJCHK(check_launch(ctx, "one-pass join"));
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));

@@ -124,7 +124,7 @@ void launch_pass_pair(hipStream_t st, const PassPairHost &h, int shift, int bits
 size_t fuse_ctl_bytes();
 u32 *fuse_join_ticket(void *d_ctl);
 void launch_fused_pass(hipStream_t st, const PassPairHost &h, int bits, int phase, int parity, void *d_ctl, u32 probe_split, u32 max_tasks,
-                       u32 table_tuples, JoinTask *d_tasks, u64 *d_counters);
+                       u32 table_tuples, JoinTask *d_tasks, u64 *d_counters, u64 *host_pub);
 constexpr int PASS_PAIR_MAX_BITS = 9;            // the write-combining scatter's range
 bool fused_two_pass_ok(int b1, int b2);
 // bucket-join kernels: JK_BKT partitions that fit one 4224-tuple table (two workgroups per CU); JK_BKT_BIG 8448-tuple

@@ -996,7 +996,7 @@ struct FuseCtl {
     u32 *ghist_next;     // the next call's copy, zeroed by this call's k_hist_fused2
     u64 *cursor_next;
 };
-struct FuseTasks { u32 probe_split, max_tasks, table_tuples, units_per_wg; JoinTask *tasks; u64 *counters; };
+struct FuseTasks { u32 probe_split, max_tasks, table_tuples, units_per_wg; JoinTask *tasks; u64 *counters; u64 *host_pub; };
 // Every counter on its own 128-byte line, the global histograms in FUSE_COPIES copies (unit u adds to copy u mod FUSE_COPIES):
 // device-scope atomics on one LINE are served one behind the other ([measured] 245 units x 256 digits x 2 relations of
 // atomics on 16 lines: 75 us for a 9 us histogram), on different lines side by side.
@@ -1144,9 +1144,11 @@ __global__ void __launch_bounds__(THREADS) k_scatter_fused2(PassPair a, int shif
         ft.tasks[slot] = t;
     }
     if (tid == 0) {
-        ft.counters[1] = (u64)(tot < ft.max_tasks ? tot : ft.max_tasks);       // ntasks
-        ft.counters[2] = maxR;
-        ft.counters[3] = maxS;
+        const u64 v[3] = {(u64)(tot < ft.max_tasks ? tot : ft.max_tasks), maxR, maxS};       // ntasks, largest partitions
+        for (int i = 0; i < 3; i++) {
+            ft.counters[1 + i] = v[i];
+            if (ft.host_pub != nullptr) __hip_atomic_store(&ft.host_pub[1 + i], v[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);   // (see bj_count_packed)
+        }
     }
 }
 
@@ -1565,7 +1567,10 @@ __device__ __forceinline__ u64 bj_readlane64(u64 v, int srclane)
 template <int BBITS>
 __device__ __forceinline__ u32 bj_bucket(u64 v, int radix_bits)
 {
-    return (u32)(((v >> radix_bits) * 0x9E3779B97F4A7C15ULL) >> (64 - BBITS));
+    // (one 32-bit multiply of the folded value: a 64 x 64-bit product is four quarter-rate multiplies, and this function runs
+    // four times per tuple in kernels bound by the instructions they issue)
+    const u64 x = v >> radix_bits;
+    return (((u32)x ^ (u32)(x >> 32)) * 0x9E3779B1u) >> (32 - BBITS);
 }
 
 // Two geometries of the same kernel:
@@ -1604,6 +1609,22 @@ __device__ __forceinline__ void bj_publish(const DirectJoin &dj, const u64 *__re
                                __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         if (threadIdx.x == 0) __hip_atomic_store(dj.done, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
+}
+
+// PACKED result counter (one-pass joins; dj.host_count set, dj.done null): counters[0] = pairs | (workgroups that are done) << 48.
+// The LAST atomicAdd a workgroup makes on the counter -- the one that reserves the range of its last tile's pairs -- also counts
+// the workgroup as done, so the workgroup whose add returns `grid - 1` in the upper bits knows the final count (what came back
+// + its own) and stores it to the pinned host word: no ticket atomic and no read-back of the counter behind the last tile
+// ([measured] two device round trips, ~5 us of a 36 us kernel at 10^6 x 10^6).  The host asks for it only when the grid is
+// below 2^16 workgroups and nR * nS < 2^48; the counters are zeroed by k_hist_fused2 of the same call.  Thread 0 only.
+constexpr int BJ_PK_SHIFT = 48;
+__device__ __forceinline__ u64 bj_count_packed(const DirectJoin &dj, u64 *__restrict__ counter, u32 add, bool last)
+{
+    const u64 v = atomicAdd((unsigned long long *)counter, (unsigned long long)add + (last ? 1ull << BJ_PK_SHIFT : 0ull));
+    const u64 base = v & ((1ull << BJ_PK_SHIFT) - 1);
+    if (last && (v >> BJ_PK_SHIFT) == (u64)gridDim.x - 1)
+        __hip_atomic_store(&dj.host_count[0], base + add, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    return base;
 }
 
 // A partitioned relation as the join kernels read it: 16-byte tuples, or the narrow {payload 8 B, rowID 4 B} arrays that
@@ -1699,6 +1720,7 @@ k_join_bkt(RelView<NARROW> R, RelView<NARROW> S, const JoinTask *__restrict__ ta
     constexpr int TILE = THREADS * EPT;
     constexpr int BPT = (CHUNK + THREADS - 1) / THREADS;            // build tuples per thread
     static_assert(EPT * NW == 64, "the (slot, wavefront) totals are scanned by one 64-lane wavefront");
+    static_assert(CHUNK + 4 < 16384, "bucket start, match mask and match count of a probe slot share one register");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     u64 *keys = reinterpret_cast<u64 *>(smem);                               // CHUNK * 8
     u64 *rids = keys + CHUNK;                                             // CHUNK * 8
@@ -1716,10 +1738,15 @@ k_join_bkt(RelView<NARROW> R, RelView<NARROW> S, const JoinTask *__restrict__ ta
         task.blen = dj.nb;
         task.build_is_S = dj.build_is_S;
     } else {
+        task = tasks[blockIdx.x];                                            // (the list has gridDim.x slots: both loads in flight together)
         const u32 nt = *ntasks;
-        if (blockIdx.x >= nt) { bj_publish(dj, out_count); return; }
-        task = tasks[blockIdx.x];
+        if (blockIdx.x >= nt) {
+            if (dj.host_count != nullptr && dj.done == nullptr) { if (threadIdx.x == 0) (void)bj_count_packed(dj, out_count, 0u, true); }
+            else bj_publish(dj, out_count);
+            return;
+        }
     }
+    const bool packed = !DIRECT && dj.host_count != nullptr && dj.done == nullptr;
     const bool build_is_S = task.build_is_S != 0;
     typedef typename RelView<NARROW>::Both Both;
     const RelView<NARROW> B = (build_is_S ? S : R).at(task.bbeg);
@@ -1784,109 +1811,169 @@ k_join_bkt(RelView<NARROW> R, RelView<NARROW> S, const JoinTask *__restrict__ ta
 #pragma unroll
                 for (int k = 0; k < EPT; k++) p[k] = PB.both(tb + (u32)k * THREADS, (u32)tid);
             }
-            u32 cnt[EPT], pre[EPT];
+            // The first four entries of a probe tuple's bucket are read unconditionally and together (entries past the bucket's end
+            // belong to the next bucket or to the rowID array behind the table: masked by len) and WHICH of them match is kept, so
+            // the write phase below neither hashes nor compares again; only a longer bucket is walked entry by entry.
+            // A slot's result in one register: bucket start (14 bits) | which of the first four entries match (4) | matches beyond
+            // them, or the whole count of a bucket scanned by the wavefront together (14).
+            u32 cf[EPT];
+            u32 coopbits = 0;                                                 // slots whose heavy buckets this wavefront scans together
+            auto matches = [](u32 v) -> u32 { return (u32)__popc((v >> 14) & 15u) + (v >> 18); };
 #pragma unroll
             for (int k = 0; k < EPT; k++) {
                 const u32 i = tb + (u32)k * THREADS + tid;
-                cnt[k] = 0;
-                u32 lo = 0, hi = 0;
+                u32 lo = 0, len = 0;
                 if (i < np) {
                     const u32 h = bj_bucket<BBITS>(p[k].payload, radix_bits);
-                    lo = off[h]; hi = off[h + 1];
+                    lo = off[h]; len = off[h + 1] - lo;
                 }
-                // A few lanes facing a long bucket (duplicate-heavy build side, e.g. Zipf FK as build) would
-                // serialise the whole workgroup: those buckets are scanned by all 64 lanes together.
-                unsigned long long heavy = __ballot(hi - lo > BJ_HEAVY);
-                const bool coop = heavy != 0 && __popcll(heavy) <= BJ_HEAVY_LANES;
-                if (!coop || hi - lo <= BJ_HEAVY)
-                    for (u32 j = lo; j < hi; j++) cnt[k] += (keys[j] == (p[k].payload | TM)) ? 1u : 0u;
-                if (coop) {
-                    while (heavy) {
-                        const int leader = __ffsll((long long)heavy) - 1;
-                        heavy &= heavy - 1;
-                        const u64 key = bj_readlane64(p[k].payload | TM, leader);
-                        const u32 l = __builtin_amdgcn_readlane(lo, leader), hh = __builtin_amdgcn_readlane(hi, leader);
-                        u32 tot = 0;
-                        for (u32 j = l; j < hh; j += 64) {
-                            const bool m = (j + lane < hh) && keys[j + lane] == key;
-                            tot += (u32)__popcll(__ballot(m));
+                const u64 pk = p[k].payload | TM;
+                const u64 e0 = keys[lo], e1 = keys[lo + 1], e2 = keys[lo + 2], e3 = keys[lo + 3];
+                u32 m4 = (len > 0 && e0 == pk ? 1u : 0u) | (len > 1 && e1 == pk ? 2u : 0u) | (len > 2 && e2 == pk ? 4u : 0u) |
+                         (len > 3 && e3 == pk ? 8u : 0u);
+                u32 xc = 0;
+                if (__ballot(len > 4)) {                                      // (wavefront-uniform) somebody's bucket goes on
+                    // A few lanes facing a long bucket (duplicate-heavy build side, e.g. Zipf FK as build) would
+                    // serialise the whole workgroup: those buckets are scanned by all 64 lanes together.
+                    unsigned long long heavy = __ballot(len > BJ_HEAVY);
+                    const bool coop = heavy != 0 && __popcll(heavy) <= BJ_HEAVY_LANES;
+                    if (!coop || len <= BJ_HEAVY)
+                        for (u32 j = lo + 4; j < lo + len; j++) xc += keys[j] == pk ? 1u : 0u;
+                    if (coop) {
+                        coopbits |= 1u << k;
+                        while (heavy) {
+                            const int leader = __ffsll((long long)heavy) - 1;
+                            heavy &= heavy - 1;
+                            const u64 key = bj_readlane64(pk, leader);
+                            const u32 l = __builtin_amdgcn_readlane(lo, leader), hh = l + __builtin_amdgcn_readlane(len, leader);
+                            u32 tot = 0;
+                            for (u32 j = l; j < hh; j += 64) {
+                                const bool m = (j + lane < hh) && keys[j + lane] == key;
+                                tot += (u32)__popcll(__ballot(m));
+                            }
+                            if (lane == leader) { m4 = 0; xc = tot; }
                         }
-                        if (lane == leader) cnt[k] = tot;
                     }
                 }
+                cf[k] = lo | (m4 << 14) | (xc << 18);
             }
-            // per slot: exclusive prefix of the match counts inside the wavefront
+            // per slot: the wavefront's matches.  (No prefix over the lanes: the pairs of a slot are written ROUND-MAJOR -- first every
+            // lane's first match, side by side, then every lane's second ... -- so a lane's position in a round is its rank among
+            // the lanes that still have a match (ballot + mbcnt), and every store instruction of the wavefront covers one
+            // contiguous range.  [measured] lane-major positions (a lane's matches side by side, lanes by prefix sum): tasks that
+            // build on the side with duplicates -- half the tasks of 10^6 x 10^6 -- spent 9.3 us writing pairs against 1.7-4.4 us
+            // for tasks with one match per probe tuple, and set the kernel's time.)
+            u32 dup = 0;
 #pragma unroll
-            for (int k = 0; k < EPT; k++) {
-                u32 tot;
-                if (__ballot(cnt[k] > 1) == 0) {                              // foreign-key case: ballot + mbcnt
-                    const unsigned long long m = __ballot(cnt[k] != 0);
-                    pre[k] = __builtin_amdgcn_mbcnt_hi((u32)(m >> 32), __builtin_amdgcn_mbcnt_lo((u32)m, 0u));
-                    tot = (u32)__popcll(m);
-                } else {
-                    const u32 inc = wave_incl_scan(cnt[k], lane);
-                    pre[k] = inc - cnt[k];
-                    tot = __shfl(inc, 63, 64);
+            for (int k = 0; k < EPT; k++) dup |= matches(cf[k]);
+            if (__ballot(dup > 1) == 0) {                                     // foreign-key case
+#pragma unroll
+                for (int k = 0; k < EPT; k++) {
+                    const unsigned long long m = __ballot(cf[k] >> 14);
+                    if (lane == 0) wtot[k * NW + w] = (u32)__popcll(m);
                 }
-                if (lane == 0) wtot[k * NW + w] = tot;
+            } else if (__ballot(dup > 7) == 0) {                              // a few duplicates: three bit planes per slot
+#pragma unroll
+                for (int k = 0; k < EPT; k++) {
+                    const u32 c = matches(cf[k]);
+                    u32 tot = 0;
+#pragma unroll
+                    for (int b = 0; b < 3; b++) tot += (u32)__popcll(__ballot((c >> b) & 1u)) << b;
+                    if (lane == 0) wtot[k * NW + w] = tot;
+                }
+            } else {
+#pragma unroll
+                for (int k = 0; k < EPT; k++) {
+                    const u32 tot = __shfl(wave_incl_scan(matches(cf[k]), lane), 63, 64);
+                    if (lane == 0) wtot[k * NW + w] = tot;
+                }
             }
             __syncthreads();
             // every wavefront scans the 64 (slot, wave) totals itself: no second barrier
             const u32 mine = wtot[lane];
             const u32 inc64 = wave_incl_scan(mine, lane);
             const u32 tile_total = __shfl(inc64, 63, 64);
-            if (tid == 0 && tile_total) *gres = atomicAdd(out_count, (u64)tile_total);
+            const bool last_tile = packed && cb + (u32)CHUNK >= nb && tb + (u32)TILE >= np;
+            if (tid == 0 && (tile_total || last_tile))
+                *gres = packed ? bj_count_packed(dj, out_count, tile_total, last_tile) : atomicAdd(out_count, (u64)tile_total);
             __syncthreads();
             if (tile_total && out != nullptr) {
                 const u64 g = *gres;
+                const u32 wu = (u32)__builtin_amdgcn_readfirstlane(w);
+                auto put = [&](u64 o, u64 prow, u64 brow) {
+                    if (o < out_capacity) {
+                        Pair pr;
+                        if (build_is_S) { pr.r = prow; pr.s = brow; }         // orderFlag, Result.cpp:64-68
+                        else            { pr.r = brow; pr.s = prow; }
+                        out[o] = pr;
+                        if (DIRECT && o < dj.host_cap) dj.host_out[o] = pr;
+                    }
+                };
+                auto rank_in = [&](unsigned long long m) -> u32 { return __builtin_amdgcn_mbcnt_hi((u32)(m >> 32), __builtin_amdgcn_mbcnt_lo((u32)m, 0u)); };
+                u32 sb[EPT];                                                  // (wavefront-uniform) the slot's next free pair, relative to g
+#pragma unroll
+                for (int k = 0; k < EPT; k++) sb[k] = (u32)__builtin_amdgcn_readlane((int)(inc64 - mine), k * NW + wu);
+                // the matches among the first four entries need no second look at the keys: one round per match, every slot of
+                // every lane writing its next one (ONE round in a foreign-key join)
+                for (;;) {
+                    u32 more = 0;
+#pragma unroll
+                    for (int k = 0; k < EPT; k++) {
+                        const u32 m4 = (coopbits >> k) & 1u ? 0u : (cf[k] >> 14) & 15u;
+                        const unsigned long long bal = __ballot(m4 != 0);
+                        if (m4) {
+                            put(g + sb[k] + rank_in(bal), probe_rowid(p[k]), rids[(cf[k] & 0x3fffu) + (u32)__builtin_ctz(m4)]);
+                            cf[k] &= ~((m4 & (0u - m4)) << 14);
+                        }
+                        sb[k] += (u32)__popcll(bal);
+                        more |= m4 & (m4 - 1);
+                    }
+                    if (!__ballot(more != 0)) break;
+                }
 #pragma unroll
                 for (int k = 0; k < EPT; k++) {
-                    const u32 sbase = __shfl(inc64 - mine, k * NW + w, 64);   // exclusive prefix of (slot k, wave w)
-                    u32 lo = 0, hi = 0;
-                    if (cnt[k]) {
-                        const u32 h = bj_bucket<BBITS>(p[k].payload, radix_bits);
-                        lo = off[h]; hi = off[h + 1];
-                    }
-                    u64 o = g + sbase + pre[k];
-                    unsigned long long heavy = __ballot(hi - lo > BJ_HEAVY);
-                    const bool coop = heavy != 0 && __popcll(heavy) <= BJ_HEAVY_LANES;
-                    if (cnt[k] && (!coop || hi - lo <= BJ_HEAVY)) {
-                        for (u32 j = lo; j < hi; j++) {
-                            if (keys[j] == (p[k].payload | TM)) {
-                                if (o < out_capacity) {
-                                    const u64 pk = probe_rowid(p[k]);
-                                    Pair pr;
-                                    if (build_is_S) { pr.r = pk; pr.s = rids[j]; }         // orderFlag, Result.cpp:64-68
-                                    else            { pr.r = rids[j]; pr.s = pk; }
-                                    out[o] = pr;
-                                    if (DIRECT && o < dj.host_cap) dj.host_out[o] = pr;
-                                }
-                                o++;
+                    const u32 lo = cf[k] & 0x3fffu;
+                    if (!((coopbits >> k) & 1u)) {                            // (wavefront-uniform)
+                        u32 xc = cf[k] >> 18;
+                        if (!__ballot(xc != 0)) continue;
+                        u32 j = lo + 4;                                       // the rest of a longer bucket, a round per match again
+                        for (;;) {
+                            const unsigned long long bal = __ballot(xc != 0);
+                            if (!bal) break;
+                            if (xc) {
+                                while (keys[j] != (p[k].payload | TM)) j++;   // (xc matches lie ahead: counted in step C)
+                                put(g + sb[k] + rank_in(bal), probe_rowid(p[k]), rids[j]);
+                                j++;
+                                xc--;
                             }
+                            sb[k] += (u32)__popcll(bal);
                         }
+                        continue;
                     }
-                    if (coop) {
-                        const unsigned long long lt = (1ull << lane) - 1ull;
-                        while (heavy) {
-                            const int leader = __ffsll((long long)heavy) - 1;
-                            heavy &= heavy - 1;
-                            const u64 key = bj_readlane64(p[k].payload | TM, leader);
-                            const u64 pkey = bj_readlane64(probe_rowid(p[k]), leader);
-                            u64 ob = bj_readlane64(o, leader);
-                            const u32 l = __builtin_amdgcn_readlane(lo, leader), hh = __builtin_amdgcn_readlane(hi, leader);
-                            for (u32 j = l; j < hh; j += 64) {
-                                const bool m = (j + lane < hh) && keys[j + lane] == key;
-                                const unsigned long long bal = __ballot(m);
-                                const u64 dst = ob + (u64)__popcll(bal & lt);
-                                if (m && dst < out_capacity) {
-                                    Pair pr;
-                                    if (build_is_S) { pr.r = pkey; pr.s = rids[j + lane]; }
-                                    else            { pr.r = rids[j + lane]; pr.s = pkey; }
-                                    out[dst] = pr;
-                                    if (DIRECT && dst < dj.host_cap) dj.host_out[dst] = pr;
-                                }
-                                ob += (u64)__popcll(bal);
-                            }
+                    // a slot with buckets scanned by the whole wavefront: lane-major positions
+                    const u32 c = matches(cf[k]);
+                    u64 o = g + sb[k] + (wave_incl_scan(c, lane) - c);
+                    u32 hi = 0;
+                    if (c) hi = off[bj_bucket<BBITS>(p[k].payload, radix_bits) + 1];
+                    const bool is_heavy = hi > lo + BJ_HEAVY;
+                    unsigned long long heavy = __ballot(is_heavy);
+                    if (c && !is_heavy) {
+                        for (u32 j = lo; j < hi; j++)
+                            if (keys[j] == (p[k].payload | TM)) put(o++, probe_rowid(p[k]), rids[j]);
+                    }
+                    const unsigned long long lt = (1ull << lane) - 1ull;
+                    while (heavy) {
+                        const int leader = __ffsll((long long)heavy) - 1;
+                        heavy &= heavy - 1;
+                        const u64 key = bj_readlane64(p[k].payload | TM, leader);
+                        const u64 pkey = bj_readlane64(probe_rowid(p[k]), leader);
+                        u64 ob = bj_readlane64(o, leader);
+                        const u32 l = __builtin_amdgcn_readlane(lo, leader), hh = __builtin_amdgcn_readlane(hi, leader);
+                        for (u32 j = l; j < hh; j += 64) {
+                            const bool m = (j + lane < hh) && keys[j + lane] == key;
+                            const unsigned long long bal = __ballot(m);
+                            if (m) put(ob + (u64)__popcll(bal & lt), pkey, rids[j + lane]);
+                            ob += (u64)__popcll(bal);
                         }
                     }
                 }
@@ -1895,7 +1982,9 @@ k_join_bkt(RelView<NARROW> R, RelView<NARROW> S, const JoinTask *__restrict__ ta
         }
         __syncthreads();         // the table is rebuilt by the next chunk
     }
-    if (!DIRECT && dj.host_count != nullptr) {
+    if (packed) {
+        if (tid == 0 && (nb == 0 || np == 0)) (void)bj_count_packed(dj, out_count, 0u, true);      // (no tile ran: a task has both sides, but)
+    } else if (!DIRECT && dj.host_count != nullptr) {
         __syncthreads();
         bj_publish(dj, out_count);
     }
@@ -2754,7 +2843,7 @@ constexpr size_t FUSE_COPY_BYTES = FUSE_CURSOR_BYTES + FUSE_GHIST_BYTES;
 size_t fuse_ctl_bytes() { return 2 * FUSE_COPY_BYTES + 256; }
 u32 *fuse_join_ticket(void *d_ctl) { return (u32 *)((unsigned char *)d_ctl + 2 * FUSE_COPY_BYTES + 128); }
 void launch_fused_pass(hipStream_t st, const PassPairHost &h, int bits, int phase, int parity, void *d_ctl, u32 probe_split, u32 max_tasks,
-                       u32 table_tuples, JoinTask *d_tasks, u64 *d_counters)
+                       u32 table_tuples, JoinTask *d_tasks, u64 *d_counters, u64 *host_pub)
 {
     allow_big_lds();
     PassPair a;
@@ -2786,7 +2875,7 @@ void launch_fused_pass(hipStream_t st, const PassPairHost &h, int bits, int phas
         if (forced_k) k = forced_k;
         if (k < 1) k = 1;
     }
-    const FuseTasks ft{probe_split, max_tasks, table_tuples, k, d_tasks, d_counters};
+    const FuseTasks ft{probe_split, max_tasks, table_tuples, k, d_tasks, d_counters, host_pub};
     if (phase == 0) {
         hipLaunchKernelGGL(k_hist_fused2, dim3((mu + k - 1) / k, 2), dim3(PART_THREADS), ((size_t)8 << bits), st, a, 0, bits, fc, ft);
     } else if (wc_threads_for(bits) == WC_THREADS_SMALL && bits <= 8) {

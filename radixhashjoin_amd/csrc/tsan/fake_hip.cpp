@@ -195,7 +195,7 @@ void launch_join(hipStream_t st, const void *, const u64 *, const void *, const 
 }
 size_t fuse_ctl_bytes() { return 12352; }
 u32 *fuse_join_ticket(void *d_ctl) { return (u32 *)((unsigned char *)d_ctl + 12288) + 1; }
-void launch_fused_pass(hipStream_t st, const PassPairHost &, int, int phase, int, void *, u32, u32, u32, JoinTask *, u64 *d_counters)
+void launch_fused_pass(hipStream_t st, const PassPairHost &, int, int phase, int, void *, u32, u32, u32, JoinTask *, u64 *d_counters, u64 *)
 {
     if (phase == 0) fake_enqueue(st, [=] { memset(d_counters, 0, 64); });           // (the histogram launch clears the join counters)
 }

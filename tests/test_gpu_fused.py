@@ -100,3 +100,26 @@ def test_host_pointer_call_takes_the_fused_path_too(eng, oracle):
     assert t["passes"] == 1 and eng.info("last.pipelined") == 0
     exp = oracle.join(R, S)
     assert np.array_equal(sorted_pairs(got), sorted_pairs(exp))
+
+
+def test_large_one_pass_join_publishes_through_the_ticket_path(eng):
+    """The packed result counter (pairs | finished workgroups << 48) is used while nR * nS < 2^48 and the grid stays below 2^16
+    workgroups; a forced one-pass plan beyond that publishes through the ticket + read-back of the counters.  17M x 17M, 9 bits:
+    33 K-tuple partitions through the chunked one-table kernel; count and checksum against the generator's closed form."""
+    n = 17_000_000
+    dR, dS, dO = eng.alloc(16 * n), eng.alloc(16 * n), eng.alloc(16 * n)
+    eng.generate(GEN_R, dR, n, 0, n)
+    eng.generate(GEN_S_UNIFORM, dS, n, 0, n, seed=5)
+    exp = eng.expected_pkfk(dS, n)
+    for _ in range(2):                                                       # (twice: the control block alternates)
+        cnt = eng.join_dev(dR, n, dS, n, dO, n, opts=Opts(1, 9))
+        assert (cnt, eng.pairs_checksum(dO, cnt)) == exp
+    t = eng.timings()
+    assert (t["passes"], t["bits1"]) == (1, 9)
+    small = 1_000_000                                                        # and a small join right behind it (packed again)
+    eng.generate(GEN_S_UNIFORM, dS, small, 0, small, seed=6)
+    exp = eng.expected_pkfk(dS, small)
+    cnt = eng.join_dev(dR, small, dS, small, dO, small)
+    assert (cnt, eng.pairs_checksum(dO, cnt)) == exp
+    for x in (dR, dS, dO):
+        x.free()

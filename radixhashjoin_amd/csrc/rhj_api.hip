@@ -448,7 +448,11 @@ int ilog2_ceil(u64 x)
 // Reference: one fixed 8-bit pass (Result.cpp:5,91).  Here: the fewest radix bits such that the
 // average build-side partition fills at most 15/16 of one LDS hash table (BJ_CHUNK), in <= 2 passes.
 // device_resident: the inputs are in HBM already (rhj_join_dev); else the host-pointer call, whose small path is one launch
-int resolve_plan(u64 nR, u64 nS, const rhj_opts *in, rhj_opts *out, bool device_resident = false)
+bool default_join_kernels(const rhj_ctx *ctx) { return ctx->opt_big_kernel < 0 && ctx->opt_big_tables < 0; }
+
+// ct13_ok: the join may pick the 6144-entry compact-table kernel for plans of 13-15 bits (default kernel choice, not the
+// multi-GPU receiver): the plan then leaves partitions of up to CT_GUARDED_UPTO tuples
+int resolve_plan(u64 nR, u64 nS, const rhj_opts *in, rhj_opts *out, bool device_resident = false, bool ct13_ok = true)
 {
     rhj_opts o;
     if (in) o = *in; else rhj_default_opts(&o);
@@ -485,6 +489,14 @@ int resolve_plan(u64 nR, u64 nS, const rhj_opts *in, rhj_opts *out, bool device_
                 // 20 slots per thread), 18 (9+9) beyond; both run in the narrow format with 16-tuple carry lines in their 9-bit passes (k_scatter_wcn
                 // <GR = 16>) and a second, 8 B/tuple histogram read of the narrow intermediate.
                 if (bits > 16) bits = nb <= (u64)65536 * 16800 ? 16 : nb <= (u64)131072 * 16800 ? 17 : 18;
+                // One bit fewer where that leaves partitions for the 6144-entry compact-table kernel (k_join_ct<.., KB = 13>, plans
+                // of 13-15 bits, average partitions of up to CT_GUARDED_UPTO tuples on both sides): half as many partitions,
+                // tasks and histogram rows.  [measured, one box, wall ms, bits as above -> one fewer] 34M 1.538 -> 1.431 . 40M 1.722 ->
+                // 1.579 . 66M 2.814 -> 2.538 . 83M 3.397 -> 2.971 . 135M 5.692 -> 5.091 . 165M 6.729 -> 6.084
+                static const bool ct13_env = env_u64("RHJ_CT13", 1, 0, 1) != 0;
+                if (ct13_ok && ct13_env && bits - 1 >= join_ct_min_radix_bits(JK_CT_G13) && bits - 1 < join_ct_min_radix_bits(JK_CT) &&
+                    (nb >> (bits - 1)) <= (u64)CT_GUARDED_UPTO && (np_ >> (bits - 1)) <= (u64)CT_GUARDED_UPTO)
+                    bits -= 1;
                 o.passes = 2; o.bits1 = (bits + 1) / 2; o.bits2 = bits / 2;
                 // 17 bits: the 9-bit pass second -- from the narrow intermediate it costs 5.3 ms per 10^9 tuples, from 16-byte
                 // tuples 7.9 ([measured] 9+8 against 8+9 at 1.5 * 10^9: 68.4 against 65.2 ms)
@@ -1495,7 +1507,7 @@ int rhj_reserve(rhj_ctx *ctx, uint64_t nR, uint64_t nS, const rhj_opts *opts)
 {
     RHJCHK(use_device(ctx));
     rhj_opts plan;
-    if (resolve_plan(nR, nS, opts, &plan) != RHJ_OK) return fail(ctx, RHJ_E_INVALID, "bad rhj_opts");
+    if (resolve_plan(nR, nS, opts, &plan, false, default_join_kernels(ctx)) != RHJ_OK) return fail(ctx, RHJ_E_INVALID, "bad rhj_opts");
     if (plan.passes >= 1) {
         RHJCHK(ensure(ctx, ctx->part_R, (size_t)(nR ? nR : 1) * 16));
         RHJCHK(ensure(ctx, ctx->part_S, (size_t)(nS ? nS : 1) * 16));
@@ -1514,7 +1526,7 @@ int rhj_join_dev(rhj_ctx *ctx, const rhj_tuple *d_R, uint64_t nR, const rhj_tupl
     if (nR == 0 || nS == 0) return RHJ_OK;            // nothing to schedule (Result.cpp:101 never fires)
     if (!d_R || !d_S) return fail(ctx, RHJ_E_INVALID, "null input relation");
     rhj_opts plan;
-    if (resolve_plan(nR, nS, opts, &plan, true) != RHJ_OK) return fail(ctx, RHJ_E_INVALID, "bad rhj_opts");
+    if (resolve_plan(nR, nS, opts, &plan, true, default_join_kernels(ctx)) != RHJ_OK) return fail(ctx, RHJ_E_INVALID, "bad rhj_opts");
     RHJCHK(partition_and_join(ctx, d_R, nR, d_S, nS, plan, d_out, d_out ? out_capacity : 0, (u64 *)out_count));
     if (d_out && *out_count > out_capacity) return fail(ctx, RHJ_E_OVERFLOW, "result buffer too small");
     return RHJ_OK;
@@ -1845,7 +1857,7 @@ int rhj_join(rhj_ctx *ctx, const rhj_tuple *R, uint64_t nR, const rhj_tuple *S, 
     if (nR == 0 || nS == 0) return RHJ_OK;
     if (!R || !S) return fail(ctx, RHJ_E_INVALID, "null input relation");
     rhj_opts plan;
-    if (resolve_plan(nR, nS, opts, &plan) != RHJ_OK) return fail(ctx, RHJ_E_INVALID, "bad rhj_opts");
+    if (resolve_plan(nR, nS, opts, &plan, false, default_join_kernels(ctx)) != RHJ_OK) return fail(ctx, RHJ_E_INVALID, "bad rhj_opts");
     if (plan.passes == 0 && is_direct(ctx, 1, nR, nS)) return join_small_host(ctx, R, nR, S, nS, out_page, (u64 *)out_count);
     {
         const int prc = join_host_pipelined(ctx, R, nR, S, nS, plan, out_page, (u64 *)out_count);
@@ -2119,7 +2131,7 @@ int rhj_join_batch(rhj_ctx *ctx, uint32_t n, const rhj_join_desc *joins, void **
         if (j.nR == 0 || j.nS == 0) continue;
         if (!j.R || !j.S) return fail(ctx, RHJ_E_INVALID, "rhj_join_batch: null input relation");
         rhj_opts plan;
-        if (resolve_plan(j.nR, j.nS, nullptr, &plan) != RHJ_OK) return fail(ctx, RHJ_E_INVALID, "bad rhj_opts");
+        if (resolve_plan(j.nR, j.nS, nullptr, &plan, false, default_join_kernels(ctx)) != RHJ_OK) return fail(ctx, RHJ_E_INVALID, "bad rhj_opts");
         (plan.passes == 0 && is_direct(ctx, 1, j.nR, j.nS) ? small : single).push_back(i);
     }
     if (!small.empty()) {
@@ -2289,7 +2301,7 @@ int rhj_shard_plan(uint64_t nR, uint64_t nS, const rhj_opts *in, rhj_opts *resol
 {
     if (!resolved) return RHJ_E_INVALID;
     rhj_opts o;
-    if (resolve_plan(nR, nS, in, &o, true) != RHJ_OK) return RHJ_E_INVALID;
+    if (resolve_plan(nR, nS, in, &o, true, false) != RHJ_OK) return RHJ_E_INVALID;     // (the receiver's join: sender tags or 16-byte partitions)
     *resolved = o;
     if (o.passes != 2 || nR < NARROW_MIN_TUPLES || nS < NARROW_MIN_TUPLES || nR >= ((u64)1 << 32) || nS >= ((u64)1 << 32)) return 0;
     if (!narrow_fused_plan(o))                          // 17-18 bits: no sender-aligned pass-2 units, so only rowIDs that need no restoring

@@ -387,8 +387,8 @@ def test_narrow_index_compact_tables_under_12_to_16_bit_plans(oracle, kind, plan
     """k_join_ct<.., KB = 13> (6144 entries {key of up to 51 bits | 13-bit arrival index}: what plans of 13-15 radix bits take for
     partitions of 2-5 K tuples since round 4) and <.., KB = 12> (4096 entries, keys of up to 52 bits: plans of 12 bits).  Forced
     here onto few, large partitions (chunks of the table, several probe tasks per partition), exactly one table and one beyond,
-    duplicates on both sides, unmatched probes; and chosen BY ITSELF for a 7+7-bit join whose partitions average 2.4 K tuples and
-    a 6+6-bit join of 3 K-tuple partitions."""
+    duplicates on both sides, unmatched probes; and chosen BY ITSELF -- plan and kernel -- for 40M and 80M tuples per side (7+6 and
+    7+7 bits, partitions of 4.9 K tuples) and a 6+6-bit join of 3 K-tuple partitions."""
     tb = plan.bits1 + plan.bits2
     table = 6_144 if kind == CT_G13 else 4_096
     e = Engine(0)
@@ -410,8 +410,9 @@ def test_narrow_index_compact_tables_under_12_to_16_bit_plans(oracle, kind, plan
             exp = oracle.join(R, S)
             assert len(got) == len(exp) and np.array_equal(sorted_pairs(got), sorted_pairs(exp))
             assert e.info("last.join_kernel") == kind
-        auto = {(7, 7): 40_000_000, (6, 6): 12_000_000}.get((plan.bits1, plan.bits2))
-        if auto and ((kind == CT_G13) == (tb == 14)):                        # the automatic choice at these sizes
+        # the automatic choice at these sizes: the plan leaves partitions of up to 5120 tuples for the 6144-entry kernel (4.9 K here)
+        auto = {(7, 6): 40_000_000, (7, 7): 80_000_000, (6, 6): 12_000_000}.get((plan.bits1, plan.bits2))
+        if auto and ((kind == CT_G13 and tb in (13, 14)) or (kind == CT_Q12 and tb == 12)):
             e.set_option("join.big_tables", -1)
             e.set_option("join.big_kernel", -1)
             e.set_option("partition.narrow", -1)

@@ -976,6 +976,18 @@ __global__ void __launch_bounds__(THREADS) k_scatter_wc2(PassPair a, int shift, 
                             blockIdx.x, nullptr, nullptr, 0, a.mix);
 }
 
+// Which side of a partition becomes the hash table.  The reference builds on the smaller bucket, S on a tie (JobScheduler.cpp:187).
+// Here a tie is "within 1/2^tie_shift of each other": the two choices then cost the same to build and to probe, and R is taken --
+// in a primary-key / foreign-key join written R JOIN S that is the side without duplicates, whose table answers every probe
+// tuple with exactly one match ([measured] timestamps inside k_join_bkt, 10^6 x 10^6: tasks that build on the side with
+// duplicates take 26 us, the others 20; with |R_k| ~ |S_k| the old rule made it a coin flip per partition).  Same pairs either way.
+__device__ __forceinline__ bool build_on_S(u64 nr, u64 ns, int tie_shift) { return nr >= ns + (ns >> tie_shift); }
+int build_tie_shift()
+{
+    static const int v = getenv("RHJ_BUILD_TIE") ? atoi(getenv("RHJ_BUILD_TIE")) : 4;      // tuning aid: 63 = the reference's rule exactly
+    return v < 1 ? 1 : v > 63 ? 63 : v;
+}
+
 // ---- one-pass joins in THREE launches (mid-size joins are launch-bound: 10^6 x 10^6 was 8 dependent launches for 77 us of
 // kernel time) ------------------------------------------------------------------------------------------------------------
 //   k_hist_fused2     per-unit histograms of R and S (grid.y = relation; unit ranges computed, no unit tables), each row also
@@ -996,7 +1008,7 @@ struct FuseCtl {
     u32 *ghist_next;     // the next call's copy, zeroed by this call's k_hist_fused2
     u64 *cursor_next;
 };
-struct FuseTasks { u32 probe_split, max_tasks, table_tuples, units_per_wg; JoinTask *tasks; u64 *counters; u64 *host_pub; };
+struct FuseTasks { u32 probe_split, max_tasks, table_tuples, units_per_wg; JoinTask *tasks; u64 *counters; u64 *host_pub; int tie_shift; };
 // Every counter on its own 128-byte line, the global histograms in FUSE_COPIES copies (unit u adds to copy u mod FUSE_COPIES):
 // device-scope atomics on one LINE are served one behind the other ([measured] 245 units x 256 digits x 2 relations of
 // atomics on 16 lines: 75 us for a 9 us histogram), on different lines side by side.
@@ -1121,7 +1133,7 @@ __global__ void __launch_bounds__(THREADS) k_scatter_fused2(PassPair a, int shif
     if (k < nbins && nr != 0 && ns != 0) {
         const u64 meanR = a.r[0].n / nbins + 1, meanS = a.r[1].n / nbins + 1;
         const bool skewR = maxR > 16 * meanR, skewS = maxS > 16 * meanS;
-        bool build_S = nr >= ns;                                    // JobScheduler.cpp:187 (+ the skew exception of k_make_tasks)
+        bool build_S = build_on_S(nr, ns, ft.tie_shift);              // (+ the skew exception of k_make_tasks)
         if (skewS && !skewR && nr <= 2 * (u64)ft.table_tuples) build_S = false;
         if (skewR && !skewS && ns <= 2 * (u64)ft.table_tuples) build_S = true;
         if (build_S) { pbeg = r0; plen = nr; bbeg = s0; blen = ns; bis = 1; }
@@ -1478,7 +1490,7 @@ k_part_max(const u64 *__restrict__ startR, const u64 *__restrict__ startS, u64 n
 __global__ void __launch_bounds__(1024)
 k_make_tasks(const u64 *__restrict__ startR, const u64 *__restrict__ startS, u64 nparts, u32 probe_split,
              JoinTask *__restrict__ tasks, u32 *__restrict__ ntasks, u32 max_tasks, u64 *__restrict__ stats,
-             u32 table_tuples, int own_max)
+             u32 table_tuples, int own_max, int tie_shift)
 {
     __shared__ u32 wsum[16];
     __shared__ u32 gbase;
@@ -1510,7 +1522,7 @@ k_make_tasks(const u64 *__restrict__ startR, const u64 *__restrict__ startS, u64
             // balanced side fits one or two LDS tables, build on it instead: one-compare probes, same pairs.
             const u64 meanR = startR[nparts] / nparts + 1, meanS = startS[nparts] / nparts + 1;
             const bool skewR = maxR > 16 * meanR, skewS = maxS > 16 * meanS;
-            bool build_S = nr >= ns;
+            bool build_S = build_on_S(nr, ns, tie_shift);
             if (skewS && !skewR && nr <= 2 * (u64)table_tuples) build_S = false;     // at most two build chunks
             if (skewR && !skewS && ns <= 2 * (u64)table_tuples) build_S = true;
             if (build_S) { pbeg = r0; plen = nr; bbeg = s0; blen = ns; bis = 1; }
@@ -2875,7 +2887,7 @@ void launch_fused_pass(hipStream_t st, const PassPairHost &h, int bits, int phas
         if (forced_k) k = forced_k;
         if (k < 1) k = 1;
     }
-    const FuseTasks ft{probe_split, max_tasks, table_tuples, k, d_tasks, d_counters, host_pub};
+    const FuseTasks ft{probe_split, max_tasks, table_tuples, k, d_tasks, d_counters, host_pub, build_tie_shift()};
     if (phase == 0) {
         hipLaunchKernelGGL(k_hist_fused2, dim3((mu + k - 1) / k, 2), dim3(PART_THREADS), ((size_t)8 << bits), st, a, 0, bits, fc, ft);
     } else if (wc_threads_for(bits) == WC_THREADS_SMALL && bits <= 8) {
@@ -3073,7 +3085,7 @@ void launch_make_tasks(hipStream_t st, const u64 *d_startR, const u64 *d_startS,
     }
     hipLaunchKernelGGL(k_make_tasks, dim3((unsigned)((nparts + 1023) / 1024)), dim3(1024), 0, st, d_startR, d_startS,
                        nparts, probe_split, d_tasks, d_ntasks, max_tasks, d_stats,
-                       join_table_tuples(kind), own_max);
+                       join_table_tuples(kind), own_max, build_tie_shift());
 }
 
 void launch_join(hipStream_t st, const void *d_R, const u64 *d_startR, const void *d_S, const u64 *d_startS,

@@ -111,7 +111,11 @@ int  rhj_set_profiling(rhj_ctx *ctx, int enabled);
  * rowID is below 2^32 (a larger one is detected on the device -- by the first histogram kernel -- and THAT join repeats itself
  * in the 16-byte format; the next join tries the narrow format again);
  * "partition.mix": -1 automatic (= 1 unless RHJ_MIX=0 is in the environment), 1: joins take their radix digits from
- * rhj_mix64(payload), 0: from the raw payload (see rhj_opts). */
+ * rhj_mix64(payload), 0: from the raw payload (see rhj_opts);
+ * "join.sniff": -1 automatic (= 1 unless RHJ_SNIFF=0), 1: a partitioned join samples the join values of both relations for
+ * duplicates while it counts them, and where the two sides of a partition are within 1/16 of each other in size the side with
+ * fewer duplicates becomes the hash table (the reference builds on the smaller bucket, S on a tie: JobScheduler.cpp:187; a table
+ * without duplicates answers every probe tuple with one match); 0: the first relation wins such a tie.  Same pairs either way. */
 int  rhj_set_option(rhj_ctx *ctx, const char *name, int64_t value);
 /* what the last join did: "last.narrow" (0 / 1 / 2, see above), "last.join_kernel" (0 one-table, 1 chunked, 2 / 3
  * compact table full / half size, 4 / 5 the same with 20 probe slots per thread, 6 / 7 the 12288- / 6144-entry geometries, 8 / 9 / 10 see "join.big_kernel", -1 none: direct small join or empty input), "last.pipelined" (the number

@@ -194,8 +194,15 @@ struct rhj_ctx {
     DevBuf fuse_ctl;                   // one-pass joins in three launches: global histograms, digit cursors, tickets (k_hist_fused2)
     bool fuse_clean = false;           // ... whose copy for the next call the kernels leave zeroed (false: the next call clears both first)
     int fuse_parity = 0;               // the copy the next call uses
+    // which side of a join has duplicate join values (DupSniff, rhj_internal.h): the sample counters of R and S for a two-pass join
+    // (a one-pass join keeps them in its control block)
+    DevBuf sniff_tab;
+    int sniff_side = -1;               // partition_relation_fused: the side it is counting for (-1: no sampling)
+    u64 sniff_n[2] = {0, 0};
+    bool sniff_ready = false;          // both sides of the current join were sampled: k_make_tasks may ask
     u64 *h_pub = nullptr, *h_pub_dev = nullptr;   // pinned: the join counters as the bucket join's last workgroup publishes them
     int opt_fused = -1;                // -1: automatic (RHJ_FUSE env, default 1), 0 / 1
+    int opt_sniff = -1;                // -1: automatic (RHJ_SNIFF env, default 1), 0 / 1: sample the join values for duplicates (DupSniff)
     std::vector<u64> shard_ps_host[2]; // the class boundaries of the last rhj_shard_stats of each side (host copy)
     DevBuf shard_peer_tab;             // rhj_shard_split_peer: delta[2^bits] u64 + owner[2^bits] u8 per side
     DevBuf shard_wide;                 // u32 per side: rhj_shard_split met a rowID - key_base >= 2^32 (checked by rhj_shard_join)
@@ -435,6 +442,13 @@ u64 env_u64(const char *name, u64 dflt, u64 lo, u64 hi)
     const u64 x = strtoull(v, &end, 10);
     if (end == v) return dflt;
     return x < lo ? lo : x > hi ? hi : x;
+}
+
+// whether joins sample their join values for duplicates (DupSniff; RHJ_SNIFF=0: no, the first relation wins every near tie)
+bool sniff_on(const rhj_ctx *ctx)
+{
+    static const bool on = env_u64("RHJ_SNIFF", 1, 0, 1) != 0;
+    return ctx->opt_sniff >= 0 ? ctx->opt_sniff != 0 : on;
 }
 
 int ilog2_ceil(u64 x)
@@ -716,10 +730,19 @@ int partition_relation_fused(rhj_ctx *ctx, const FusedIn &in, u64 n, int b1, int
         else launch_init_single_segment(st, n, g1.L, seg0, unit_start1);          // seg0 = {0,n}, unit_start1 = {0, units1}
         HIPCHK(ctx, hipMemsetAsync(x_hist2.p, 0, (size_t)units2 * nb2 * 4, st));
     }
+    DupSniff sn;
+    if (ctx->sniff_side >= 0 && !segs) {                // a join's relation: sample its join values for duplicates
+        const int side = ctx->sniff_side;
+        sn.tab = (u32 *)ctx->sniff_tab.p + (size_t)side * SNIFF_SLOTS;
+        sn.sel_bits = sniff_sel_bits(n);
+        ctx->sniff_n[side] = n;
+        Span s(ctx, RHJ_K_AUX);
+        HIPCHK(ctx, hipMemsetAsync(sn.tab, 0, (size_t)SNIFF_SLOTS * 4, st));
+    }
     {
         Span s(ctx, RHJ_K_HIST);                        // (16-byte input: also reports a rowID that does not fit the narrow format)
         launch_hist2d_units(st, segs ? (const void *)in.P : in.aos, segs, n, g1.L, units1, b1, b2, per, ngroups,
-                            (u32 *)x_unit_hist.p, (u32 *)x_hist2.p, 0, wide, rng1, g1.mix);
+                            (u32 *)x_unit_hist.p, (u32 *)x_hist2.p, 0, wide, rng1, g1.mix, sn);
     }
     {
         Span s(ctx, RHJ_K_SCAN);
@@ -949,6 +972,7 @@ bool two_streams_ok(const rhj_ctx *ctx, u64 nR, u64 nS, const rhj_opts &plan, st
 int partition_phase(rhj_ctx *ctx, const void *d_R, u64 nR, const void *d_S, u64 nS, const rhj_opts &plan,
                     std::function<int()> *before_S = nullptr)
 {
+    ctx->sniff_ready = false;
     auto s_ready = [&]() -> int {
         if (!before_S || !*before_S) return RHJ_OK;
         std::function<int()> f;
@@ -1001,17 +1025,33 @@ int partition_phase(rhj_ctx *ctx, const void *d_R, u64 nR, const void *d_S, u64 
                 HIPCHK(ctx, hipStreamCreateWithFlags(&ctx->aux_stream, hipStreamNonBlocking));
                 for (int i = 0; i < 2; i++) HIPCHK(ctx, hipEventCreateWithFlags(&ctx->aux_ev[i], hipEventDisableTiming));
             }
+            const bool sniff = sniff_on(ctx);
+            if (sniff) RHJCHK(ensure(ctx, ctx->sniff_tab, (size_t)2 * SNIFF_SLOTS * 4));
             HIPCHK(ctx, hipEventRecord(ctx->aux_ev[0], ctx->stream));             // (the inputs, the cleared flag: everything so far)
             HIPCHK(ctx, hipStreamWaitEvent(ctx->aux_stream, ctx->aux_ev[0], 0));
             const PartScratch s2 = second_scratch(ctx);
-            RHJCHK(partition_relation_fused(ctx, d_R, nR, plan.bits1, plan.bits2, ctx->part_R.p, (u64 *)ctx->ps_R.p, ctx->cur_narrow, mix));
-            RHJCHK(partition_relation_fused(ctx, d_S, nS, plan.bits1, plan.bits2, ctx->part_S.p, (u64 *)ctx->ps_S.p, ctx->cur_narrow, mix, &s2));
+            ctx->sniff_side = sniff ? 0 : -1;
+            int prc = partition_relation_fused(ctx, d_R, nR, plan.bits1, plan.bits2, ctx->part_R.p, (u64 *)ctx->ps_R.p, ctx->cur_narrow, mix);
+            ctx->sniff_side = sniff ? 1 : -1;
+            if (prc == RHJ_OK)
+                prc = partition_relation_fused(ctx, d_S, nS, plan.bits1, plan.bits2, ctx->part_S.p, (u64 *)ctx->ps_S.p, ctx->cur_narrow, mix, &s2);
+            ctx->sniff_side = -1;
+            RHJCHK(prc);
+            ctx->sniff_ready = sniff;
             HIPCHK(ctx, hipEventRecord(ctx->aux_ev[1], ctx->aux_stream));
             HIPCHK(ctx, hipStreamWaitEvent(ctx->stream, ctx->aux_ev[1], 0));
         } else if (ctx->cur_narrow) {
-            RHJCHK(partition_relation_fused(ctx, d_R, nR, plan.bits1, plan.bits2, ctx->part_R.p, (u64 *)ctx->ps_R.p, ctx->cur_narrow, mix));
-            RHJCHK(s_ready());
-            RHJCHK(partition_relation_fused(ctx, d_S, nS, plan.bits1, plan.bits2, ctx->part_S.p, (u64 *)ctx->ps_S.p, ctx->cur_narrow, mix));
+            const bool sniff = sniff_on(ctx);
+            if (sniff) RHJCHK(ensure(ctx, ctx->sniff_tab, (size_t)2 * SNIFF_SLOTS * 4));
+            ctx->sniff_side = sniff ? 0 : -1;
+            int prc = partition_relation_fused(ctx, d_R, nR, plan.bits1, plan.bits2, ctx->part_R.p, (u64 *)ctx->ps_R.p, ctx->cur_narrow, mix);
+            if (prc == RHJ_OK) prc = s_ready();
+            ctx->sniff_side = sniff ? 1 : -1;
+            if (prc == RHJ_OK)
+                prc = partition_relation_fused(ctx, d_S, nS, plan.bits1, plan.bits2, ctx->part_S.p, (u64 *)ctx->ps_S.p, ctx->cur_narrow, mix);
+            ctx->sniff_side = -1;
+            RHJCHK(prc);
+            ctx->sniff_ready = sniff;
         } else if (plan.passes == 1 && plan.bits1 <= PASS_PAIR_MAX_BITS) {
             RHJCHK(s_ready());
             RHJCHK(run_pass_pair(ctx, d_R, nR, ctx->part_R.p, (u64 *)ctx->ps_R.p, d_S, nS, ctx->part_S.p, (u64 *)ctx->ps_S.p,
@@ -1077,8 +1117,15 @@ int join_phase_on(rhj_ctx *ctx, const void *d_Rp, const u64 *d_psR, u64 nR, cons
     } else {
         {
             Span s(ctx, RHJ_K_TASKS);
+            SniffVerdict sv;                                        // (the partition phase of THIS join sampled both sides: ask them)
+            if (ctx->sniff_ready && ctx->sniff_n[0] == nR && ctx->sniff_n[1] == nS) {
+                sv.tab = (const u32 *)ctx->sniff_tab.p;
+                sv.expect_R = (u32)(nR >> sniff_sel_bits(nR));
+                sv.expect_S = (u32)(nS >> sniff_sel_bits(nS));
+            }
+            ctx->sniff_ready = false;
             launch_make_tasks(ctx->stream, d_psR, d_psS, nparts, probe_split, (JoinTask *)ctx->tasks.p, d_ntasks, max_tasks,
-                              d_count + 2, kind);                   // counters[2..3]: largest partition of R, S
+                              d_count + 2, kind, sv);               // counters[2..3]: largest partition of R, S
         }
         {
             Span s(ctx, RHJ_K_JOIN);
@@ -1210,7 +1257,7 @@ int join_one_pass_fused(rhj_ctx *ctx, const void *d_R, u64 nR, const void *d_S, 
     for (int phase = 0; phase < 2; phase++) {
         Span s(ctx, phase == 0 ? RHJ_K_HIST : RHJ_K_SCATTER);
         launch_fused_pass(ctx->stream, h, bits, phase, parity, ctx->fuse_ctl.p, probe_split, max_tasks, join_table_tuples(kind),
-                          (JoinTask *)ctx->tasks.p, d_count, ctx->h_pub_dev);
+                          (JoinTask *)ctx->tasks.p, d_count, ctx->h_pub_dev, sniff_on(ctx));
     }
     // the packed result counter (rhj_kernels.hip bj_count_packed) while pairs and workgroups fit its two fields
     const bool packed = max_tasks < (1u << 16) && (double)nR * (double)nS < 2.8e14;
@@ -1368,7 +1415,7 @@ int rhj_release_workspace(rhj_ctx *ctx)
                      &ctx->unit_start_b, &ctx->unit_hist_b, &ctx->unit_base_b, &ctx->scan_tmp_b, &ctx->tasks,
                      &ctx->counters, &ctx->out_pairs, &ctx->small_out, &ctx->hist_tmp, &ctx->scan_tmp, &ctx->hist2,
                      &ctx->grp_rng, &ctx->unit_start2, &ctx->narrow_flag, &ctx->seg_rng, &ctx->tag_base,
-                     &ctx->shard_ps[0], &ctx->shard_ps[1], &ctx->shard_mm, &ctx->shard_wide, &ctx->shard_peer_tab, &ctx->fuse_ctl, &ctx->hist2_b, &ctx->grp_rng_b,
+                     &ctx->shard_ps[0], &ctx->shard_ps[1], &ctx->shard_mm, &ctx->shard_wide, &ctx->shard_peer_tab, &ctx->fuse_ctl, &ctx->sniff_tab, &ctx->hist2_b, &ctx->grp_rng_b,
                      &ctx->unit_start2_b, &ctx->ps_1_b, &ctx->part_tmp_b, &ctx->b_in[0], &ctx->b_out[0], &ctx->b_cnt[0],
                      &ctx->b_in[1], &ctx->b_out[1], &ctx->b_cnt[1]};
     ctx->fuse_clean = false;
@@ -1434,6 +1481,7 @@ int rhj_set_option(rhj_ctx *ctx, const char *name, int64_t value)
     }
     if (n == "partition.mix" && value >= -1 && value <= 1) { ctx->opt_mix = (int)value; return RHJ_OK; }
     if (n == "join.fused" && value >= -1 && value <= 1) { ctx->opt_fused = (int)value; return RHJ_OK; }
+    if (n == "join.sniff" && value >= -1 && value <= 1) { ctx->opt_sniff = (int)value; return RHJ_OK; }
     return fail(ctx, RHJ_E_INVALID, "rhj_set_option: unknown option or value: " + n);
 }
 

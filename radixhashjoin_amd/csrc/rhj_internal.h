@@ -74,12 +74,24 @@ void launch_scan_units(hipStream_t st, const PassGeom &g, const u64 *d_seg_start
                        const u32 *d_unit_hist, u64 *d_unit_base, u64 *d_part_start, u64 *d_scan_tmp);
 void launch_scatter_units(hipStream_t st, const void *d_in, void *d_out, const PassGeom &g,
                           const u64 *d_seg_start, const u32 *d_unit_start, const u64 *d_unit_base);
+// DupSniff: which side of a join has duplicate join values -- asked of the data, by the histogram kernels that read every tuple
+// anyway.  A tuple whose mix64(payload) has sel_bits leading zero bits is SAMPLED (a fixed subset of the VALUES, so every
+// duplicate of a sampled value is sampled too; sel_bits such that 256-512 tuples of the relation are) and counted in one of
+// SNIFF_SLOTS counters of its side by a hash of the value: fire-and-forget atomics, nothing waits for them.  The task planners
+// (k_make_tasks, the planner workgroup of k_scatter_fused2) sum max(0, counter - 1) per side -- duplicates, plus the few
+// chance meetings of two values in a slot, the same for both sides -- compare the two RATES, and let the side with fewer
+// duplicates be the hash table when the sizes are near (build_on_S in rhj_kernels.hip).  The counters are zero when a join
+// starts (the caller clears them, or the previous join's histogram launch did).  tab == nullptr: no sampling / the first relation.
+constexpr u32 SNIFF_SLOTS = 16384, SNIFF_TARGET = 512;
+struct DupSniff { u32 *tab = nullptr; int sel_bits = 0; };
+struct SniffVerdict { const u32 *tab = nullptr; u32 expect_R = 0, expect_S = 0; };   // tab: [2 sides][SNIFF_SLOTS]; expected samples
+inline int sniff_sel_bits(u64 n) { int s = 0; while ((n >> s) > SNIFF_TARGET) s++; return s; }
 void launch_diff_hist(hipStream_t st, const u64 *d_start, u64 nbins, u64 *d_hist);
 void launch_check_radix(hipStream_t st, const void *d_R, const u64 *d_startR, const void *d_S, const u64 *d_startS, u64 nparts,
                         int radix_bits, u64 *d_bad);
 void launch_prefix(hipStream_t st, const u64 *d_hist, u64 nbins, u64 *d_start);
 void launch_make_tasks(hipStream_t st, const u64 *d_startR, const u64 *d_startS, u64 nparts, u32 probe_split,
-                       JoinTask *d_tasks, u32 *d_ntasks, u32 max_tasks, u64 *d_stats, int kind);
+                       JoinTask *d_tasks, u32 *d_ntasks, u32 max_tasks, u64 *d_stats, int kind, const SniffVerdict &sniff = SniffVerdict());
 void launch_join(hipStream_t st, const void *d_R, const u64 *d_startR, const void *d_S, const u64 *d_startS,
                  const JoinTask *d_tasks, const u32 *d_ntasks, u32 grid, int radix_bits,
                  void *d_out, u64 out_capacity, u64 *d_out_count, int kind, const u32 *d_RK = nullptr, const u32 *d_SK = nullptr,
@@ -123,8 +135,9 @@ void launch_pass_pair(hipStream_t st, const PassPairHost &h, int shift, int bits
 // arguments to both); parity: which of the two copies of the control block this call uses (the caller alternates)
 size_t fuse_ctl_bytes();
 u32 *fuse_join_ticket(void *d_ctl);
+// sniff: sample the join values for duplicates (DupSniff; the counters live in the control block)
 void launch_fused_pass(hipStream_t st, const PassPairHost &h, int bits, int phase, int parity, void *d_ctl, u32 probe_split, u32 max_tasks,
-                       u32 table_tuples, JoinTask *d_tasks, u64 *d_counters, u64 *host_pub);
+                       u32 table_tuples, JoinTask *d_tasks, u64 *d_counters, u64 *host_pub, bool sniff = false);
 constexpr int PASS_PAIR_MAX_BITS = 9;            // the write-combining scatter's range
 bool fused_two_pass_ok(int b1, int b2);
 // bucket-join kernels: JK_BKT partitions that fit one 4224-tuple table (two workgroups per CU); JK_BKT_BIG 8448-tuple
@@ -143,7 +156,7 @@ int join_ct_min_radix_bits(int kind = JK_CT);   // 16: keys of 48 bits beside a 
 // rowID - key_base does not fit 32 bits.  d_unit_rng (may be null): explicit pass-1 units (launch_seg_units).
 void launch_hist2d_units(hipStream_t st, const void *d_in, bool in_narrow, u64 n, u64 L, u32 units, int b1, int b2,
                          u32 units_per_group, u32 ngroups, u32 *d_hist1, u32 *d_hist2, u64 key_base, u32 *d_wide,
-                         const u64 *d_unit_rng, int mix = 0);
+                         const u64 *d_unit_rng, int mix = 0, const DupSniff &sniff = DupSniff());
 void launch_seg_units(hipStream_t st, u32 nseg, const u64 *seg_off, const u64 *seg_L, u32 units_per_seg, u64 *d_unit_rng,
                       u64 *d_seg_start, u32 *d_unit_start);
 int seg_max();                                             // segments (= ranks) a receiver can tell apart: 16

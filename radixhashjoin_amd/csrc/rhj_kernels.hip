@@ -311,11 +311,44 @@ constexpr int H2_THREADS = 1024;
 // pass-2 unit, holds tuples of ONE sender).  Null: unit u = rows [u * L, (u+1) * L).  Group = u / units_per_group either way.
 
 // IN_NARROW: the input is a payload array (8 B/tuple; a received narrow shard), no rowIDs to inspect.
+// DupSniff (rhj_internal.h): m = mix64(payload)
+__device__ __forceinline__ void sniff_sample(const DupSniff &sn, u64 m)
+{
+    if (sn.sel_bits > 0 && (m >> (64 - sn.sel_bits)) != 0) return;
+    const u64 m2 = mix64(m ^ 0xA5A5A5A5A5A5A5A5ull);             // (bits of its own for the slot: the sampled values share their top bits)
+    (void)__hip_atomic_fetch_add(&sn.tab[(u32)m2 & (SNIFF_SLOTS - 1)], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+// the planners' question: does R have no more duplicates (per sampled tuple) than S?  Called by EVERY thread of the workgroup
+// (barriers inside); sh: two words of LDS.
+__device__ __forceinline__ bool sniff_prefers_R(const SniffVerdict &sv, u32 *sh)
+{
+    if (sv.tab == nullptr) return true;
+    if (threadIdx.x < 2) sh[threadIdx.x] = 0;
+    __syncthreads();
+#pragma unroll
+    for (int side = 0; side < 2; side++) {
+        u32 d = 0;
+        const uint4 *t4 = reinterpret_cast<const uint4 *>(sv.tab + (size_t)side * SNIFF_SLOTS);
+#pragma unroll 8
+        for (u32 i = threadIdx.x; i < SNIFF_SLOTS / 4; i += blockDim.x) {           // (independent 16-byte loads: in flight together)
+            const uint4 c = t4[i];
+            d += (c.x > 1 ? c.x - 1 : 0) + (c.y > 1 ? c.y - 1 : 0) + (c.z > 1 ? c.z - 1 : 0) + (c.w > 1 ? c.w - 1 : 0);
+        }
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) d += __shfl_down(d, off, 64);
+        if ((threadIdx.x & 63) == 0 && d) atomicAdd(&sh[side], d);
+    }
+    __syncthreads();
+    const u64 dR = sh[0], dS = sh[1];
+    __syncthreads();                                             // (sh belongs to the caller again)
+    return dR * (u64)sv.expect_S <= dS * (u64)sv.expect_R;
+}
+
 template <bool IN_NARROW>
 __global__ void __launch_bounds__(H2_THREADS)
 k_hist2d_units(const Tup *__restrict__ in, const u64 *__restrict__ inP, u64 n, u64 L, int b1, int b2, u32 units_per_group,
                u32 ngroups, u32 *__restrict__ hist1, u32 *__restrict__ hist2, u64 key_base, u32 *__restrict__ wide,
-               const u64 *__restrict__ unit_rng, int mix)
+               const u64 *__restrict__ unit_rng, int mix, DupSniff sn)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const u32 nb1 = 1u << b1, nb2 = 1u << b2, nbin = nb1 * nb2;
@@ -338,6 +371,7 @@ k_hist2d_units(const Tup *__restrict__ in, const u64 *__restrict__ inP, u64 n, u
 
     auto count = [&](u64 payload) {
         if (!IN_NARROW && mix) payload = mix64(payload);      // (16-byte input inside a join: digits of the mixed payload)
+        if (!IN_NARROW && sn.tab != nullptr) sniff_sample(sn, mix ? payload : mix64(payload));
         const u32 d1 = (u32)payload & m1, d2 = (u32)(payload >> b1) & m2;
         const u32 bin = (d1 << b2) | d2, sh = (bin & 1u) * 16u;
         const u32 old = atomicAdd(&tab[bin >> 1], 1u << sh);
@@ -981,7 +1015,10 @@ __global__ void __launch_bounds__(THREADS) k_scatter_wc2(PassPair a, int shift, 
 // in a primary-key / foreign-key join written R JOIN S that is the side without duplicates, whose table answers every probe
 // tuple with exactly one match ([measured] timestamps inside k_join_bkt, 10^6 x 10^6: tasks that build on the side with
 // duplicates take 26 us, the others 20; with |R_k| ~ |S_k| the old rule made it a coin flip per partition).  Same pairs either way.
-__device__ __forceinline__ bool build_on_S(u64 nr, u64 ns, int tie_shift) { return nr >= ns + (ns >> tie_shift); }
+__device__ __forceinline__ bool build_on_S(u64 nr, u64 ns, int tie_shift, bool prefer_R)
+{
+    return prefer_R ? nr >= ns + (ns >> tie_shift) : nr + (nr >> tie_shift) >= ns;
+}
 int build_tie_shift()
 {
     static const int v = getenv("RHJ_BUILD_TIE") ? atoi(getenv("RHJ_BUILD_TIE")) : 4;      // tuning aid: 63 = the reference's rule exactly
@@ -1007,8 +1044,10 @@ struct FuseCtl {
     u64 *cursor;         // [2][512] tuples of the digit already placed
     u32 *ghist_next;     // the next call's copy, zeroed by this call's k_hist_fused2
     u64 *cursor_next;
+    u32 *sniff, *sniff_next; // [2][SNIFF_SLOTS] counters of the sampled join values (DupSniff), this call's (null: no sampling) and the next's
+    int sel_bits[2];
 };
-struct FuseTasks { u32 probe_split, max_tasks, table_tuples, units_per_wg; JoinTask *tasks; u64 *counters; u64 *host_pub; int tie_shift; };
+struct FuseTasks { u32 probe_split, max_tasks, table_tuples, units_per_wg; JoinTask *tasks; u64 *counters; u64 *host_pub; int tie_shift; SniffVerdict sniff; };
 // Every counter on its own 128-byte line, the global histograms in FUSE_COPIES copies (unit u adds to copy u mod FUSE_COPIES):
 // device-scope atomics on one LINE are served one behind the other ([measured] 245 units x 256 digits x 2 relations of
 // atomics on 16 lines: 75 us for a 9 us histogram), on different lines side by side.
@@ -1027,12 +1066,22 @@ k_hist_fused2(PassPair a, int shift, int bits, FuseCtl fc, FuseTasks ft)
         const u32 gthreads = gridDim.x * gridDim.y * PART_THREADS, gid = (blockIdx.y * gridDim.x + blockIdx.x) * PART_THREADS + tid;
         for (u32 i = gid; i < 2u * FUSE_COPIES * FUSE_MAX_BINS; i += gthreads) fc.ghist_next[(size_t)i * FUSE_STRIDE32] = 0;
         for (u32 i = gid; i < 2u * FUSE_MAX_BINS; i += gthreads) fc.cursor_next[(size_t)i * FUSE_STRIDE64] = 0;
+        for (u32 i = gid; i < 2u * SNIFF_SLOTS; i += gthreads) fc.sniff_next[i] = 0;
         if (gid < 8) ft.counters[gid] = 0;
+    }
+    DupSniff sn;
+    if (fc.sniff != nullptr) {
+        sn.tab = fc.sniff + (size_t)blockIdx.y * SNIFF_SLOTS;
+        sn.sel_bits = fc.sel_bits[blockIdx.y];
     }
     // a workgroup counts ft.units_per_wg consecutive units (a row each, for the scatter) and adds their SUM to the global
     // histogram once: device-scope atomics are the scarce thing here ([measured] ~7 per ns over the whole chip)
     u32 *wtot_ = cnt + nbins;                                        // this workgroup's sum over its units
-    auto dig = [&](u64 p) -> u32 { return (u32)((a.mix ? mix64(p) : p) >> shift) & mask; };
+    auto dig = [&](u64 p) -> u32 {
+        const u64 m = a.mix ? mix64(p) : p;
+        if (sn.tab != nullptr) sniff_sample(sn, a.mix ? m : mix64(p));
+        return (u32)(m >> shift) & mask;
+    };
     const u32 u0 = blockIdx.x * ft.units_per_wg;
     if ((u64)u0 * x.L >= x.n) return;
     for (u32 b = tid; b < nbins; b += PART_THREADS) wtot_[b] = 0;
@@ -1130,10 +1179,11 @@ __global__ void __launch_bounds__(THREADS) k_scatter_fused2(PassPair a, int shif
     for (int i = 0; i < THREADS / 64; i++) { maxR = wmax[0][i] > maxR ? wmax[0][i] : maxR; maxS = wmax[1][i] > maxS ? wmax[1][i] : maxS; }
     u32 nt = 0, bis = 0;
     u64 pbeg = 0, plen = 0, bbeg = 0, blen = 0;
+    const bool prefer_R = sniff_prefers_R(ft.sniff, wsum);         // (wsum: free between the scans)
     if (k < nbins && nr != 0 && ns != 0) {
         const u64 meanR = a.r[0].n / nbins + 1, meanS = a.r[1].n / nbins + 1;
         const bool skewR = maxR > 16 * meanR, skewS = maxS > 16 * meanS;
-        bool build_S = build_on_S(nr, ns, ft.tie_shift);              // (+ the skew exception of k_make_tasks)
+        bool build_S = build_on_S(nr, ns, ft.tie_shift, prefer_R);    // (+ the skew exception of k_make_tasks)
         if (skewS && !skewR && nr <= 2 * (u64)ft.table_tuples) build_S = false;
         if (skewR && !skewS && ns <= 2 * (u64)ft.table_tuples) build_S = true;
         if (build_S) { pbeg = r0; plen = nr; bbeg = s0; blen = ns; bis = 1; }
@@ -1490,12 +1540,14 @@ k_part_max(const u64 *__restrict__ startR, const u64 *__restrict__ startS, u64 n
 __global__ void __launch_bounds__(1024)
 k_make_tasks(const u64 *__restrict__ startR, const u64 *__restrict__ startS, u64 nparts, u32 probe_split,
              JoinTask *__restrict__ tasks, u32 *__restrict__ ntasks, u32 max_tasks, u64 *__restrict__ stats,
-             u32 table_tuples, int own_max, int tie_shift)
+             u32 table_tuples, int own_max, int tie_shift, SniffVerdict sniff)
 {
     __shared__ u32 wsum[16];
     __shared__ u32 gbase;
     __shared__ u64 wmax[2][16];
     const u64 k = (u64)blockIdx.x * 1024 + threadIdx.x;
+    const bool prefer_R = sniff_prefers_R(sniff, wsum);
+    __syncthreads();
     u64 maxR = 0, maxS = 0;
     if (own_max) {                                     // one workgroup covers every partition: k_part_max's job done here
         u64 mr = k < nparts ? startR[k + 1] - startR[k] : 0, ms = k < nparts ? startS[k + 1] - startS[k] : 0;
@@ -1522,7 +1574,7 @@ k_make_tasks(const u64 *__restrict__ startR, const u64 *__restrict__ startS, u64
             // balanced side fits one or two LDS tables, build on it instead: one-compare probes, same pairs.
             const u64 meanR = startR[nparts] / nparts + 1, meanS = startS[nparts] / nparts + 1;
             const bool skewR = maxR > 16 * meanR, skewS = maxS > 16 * meanS;
-            bool build_S = build_on_S(nr, ns, tie_shift);
+            bool build_S = build_on_S(nr, ns, tie_shift, prefer_R);
             if (skewS && !skewR && nr <= 2 * (u64)table_tuples) build_S = false;     // at most two build chunks
             if (skewR && !skewS && ns <= 2 * (u64)table_tuples) build_S = true;
             if (build_S) { pbeg = r0; plen = nr; bbeg = s0; blen = ns; bis = 1; }
@@ -2851,11 +2903,12 @@ void launch_pass_pair(hipStream_t st, const PassPairHost &h, int shift, int bits
 // between calls (see FuseCtl).  phase 0: histogram + boundaries + task list; phase 1: scatter.
 constexpr size_t FUSE_CURSOR_BYTES = (size_t)2 * FUSE_MAX_BINS * FUSE_STRIDE64 * 8;
 constexpr size_t FUSE_GHIST_BYTES = (size_t)2 * FUSE_COPIES * FUSE_MAX_BINS * FUSE_STRIDE32 * 4;
-constexpr size_t FUSE_COPY_BYTES = FUSE_CURSOR_BYTES + FUSE_GHIST_BYTES;
+constexpr size_t FUSE_SNIFF_BYTES = (size_t)2 * SNIFF_SLOTS * 4;
+constexpr size_t FUSE_COPY_BYTES = FUSE_CURSOR_BYTES + FUSE_GHIST_BYTES + FUSE_SNIFF_BYTES;
 size_t fuse_ctl_bytes() { return 2 * FUSE_COPY_BYTES + 256; }
 u32 *fuse_join_ticket(void *d_ctl) { return (u32 *)((unsigned char *)d_ctl + 2 * FUSE_COPY_BYTES + 128); }
 void launch_fused_pass(hipStream_t st, const PassPairHost &h, int bits, int phase, int parity, void *d_ctl, u32 probe_split, u32 max_tasks,
-                       u32 table_tuples, JoinTask *d_tasks, u64 *d_counters, u64 *host_pub)
+                       u32 table_tuples, JoinTask *d_tasks, u64 *d_counters, u64 *host_pub, bool sniff)
 {
     allow_big_lds();
     PassPair a;
@@ -2875,6 +2928,15 @@ void launch_fused_pass(hipStream_t st, const PassPairHost &h, int bits, int phas
     fc.ghist = (u32 *)(mine + FUSE_CURSOR_BYTES);
     fc.cursor_next = (u64 *)next;
     fc.ghist_next = (u32 *)(next + FUSE_CURSOR_BYTES);
+    fc.sniff = sniff ? (u32 *)(mine + FUSE_CURSOR_BYTES + FUSE_GHIST_BYTES) : nullptr;
+    fc.sniff_next = (u32 *)(next + FUSE_CURSOR_BYTES + FUSE_GHIST_BYTES);
+    SniffVerdict sv;
+    for (int i = 0; i < 2; i++) fc.sel_bits[i] = sniff_sel_bits(h.side[i].g.n);
+    if (sniff) {
+        sv.tab = fc.sniff;
+        sv.expect_R = (u32)(h.side[0].g.n >> fc.sel_bits[0]);
+        sv.expect_S = (u32)(h.side[1].g.n >> fc.sel_bits[1]);
+    }
     u32 k = 1;
     if (phase == 0) {
         // units per workgroup: as few global-histogram atomics as a full chip allows (>= ~2 workgroups per CU stay)
@@ -2887,7 +2949,7 @@ void launch_fused_pass(hipStream_t st, const PassPairHost &h, int bits, int phas
         if (forced_k) k = forced_k;
         if (k < 1) k = 1;
     }
-    const FuseTasks ft{probe_split, max_tasks, table_tuples, k, d_tasks, d_counters, host_pub, build_tie_shift()};
+    const FuseTasks ft{probe_split, max_tasks, table_tuples, k, d_tasks, d_counters, host_pub, build_tie_shift(), sv};
     if (phase == 0) {
         hipLaunchKernelGGL(k_hist_fused2, dim3((mu + k - 1) / k, 2), dim3(PART_THREADS), ((size_t)8 << bits), st, a, 0, bits, fc, ft);
     } else if (wc_threads_for(bits) == WC_THREADS_SMALL && bits <= 8) {
@@ -2902,7 +2964,7 @@ bool fused_two_pass_ok(int b1, int b2) { return b1 >= 1 && b2 >= 1 && b1 <= WC_M
 
 void launch_hist2d_units(hipStream_t st, const void *d_in, bool in_narrow, u64 n, u64 L, u32 units, int b1, int b2,
                          u32 units_per_group, u32 ngroups, u32 *d_hist1, u32 *d_hist2, u64 key_base, u32 *d_wide,
-                         const u64 *d_unit_rng, int mix)
+                         const u64 *d_unit_rng, int mix, const DupSniff &sniff)
 {
     static std::once_flag once[64];
     const size_t lds = ((size_t)1 << (b1 + b2)) * 2 + ((size_t)4 << b1);
@@ -2913,10 +2975,10 @@ void launch_hist2d_units(hipStream_t st, const void *d_in, bool in_narrow, u64 n
     if (units == 0) return;
     if (in_narrow)
         hipLaunchKernelGGL(k_hist2d_units<true>, dim3(units), dim3(H2_THREADS), lds, st, (const Tup *)nullptr, (const u64 *)d_in, n,
-                           L, b1, b2, units_per_group, ngroups, d_hist1, d_hist2, (u64)0, (u32 *)nullptr, d_unit_rng, 0);
+                           L, b1, b2, units_per_group, ngroups, d_hist1, d_hist2, (u64)0, (u32 *)nullptr, d_unit_rng, 0, DupSniff());
     else
         hipLaunchKernelGGL(k_hist2d_units<false>, dim3(units), dim3(H2_THREADS), lds, st, (const Tup *)d_in, (const u64 *)nullptr, n,
-                           L, b1, b2, units_per_group, ngroups, d_hist1, d_hist2, key_base, d_wide, d_unit_rng, mix);
+                           L, b1, b2, units_per_group, ngroups, d_hist1, d_hist2, key_base, d_wide, d_unit_rng, mix, sniff);
 }
 
 // pass-1 units cut at segment boundaries (multi-GPU receiver); d_unit_rng gets nseg * units_per_seg + 1 entries
@@ -3075,7 +3137,7 @@ void launch_prefix(hipStream_t st, const u64 *d_hist, u64 nbins, u64 *d_start)
 }
 
 void launch_make_tasks(hipStream_t st, const u64 *d_startR, const u64 *d_startS, u64 nparts, u32 probe_split,
-                       JoinTask *d_tasks, u32 *d_ntasks, u32 max_tasks, u64 *d_stats, int kind)
+                       JoinTask *d_tasks, u32 *d_ntasks, u32 max_tasks, u64 *d_stats, int kind, const SniffVerdict &sniff)
 {
     const int own_max = nparts <= 1024 ? 1 : 0;        // a single workgroup of k_make_tasks sees every partition
     if (!own_max) {
@@ -3085,7 +3147,7 @@ void launch_make_tasks(hipStream_t st, const u64 *d_startR, const u64 *d_startS,
     }
     hipLaunchKernelGGL(k_make_tasks, dim3((unsigned)((nparts + 1023) / 1024)), dim3(1024), 0, st, d_startR, d_startS,
                        nparts, probe_split, d_tasks, d_ntasks, max_tasks, d_stats,
-                       join_table_tuples(kind), own_max, build_tie_shift());
+                       join_table_tuples(kind), own_max, build_tie_shift(), sniff);
 }
 
 void launch_join(hipStream_t st, const void *d_R, const u64 *d_startR, const void *d_S, const u64 *d_startS,

@@ -169,7 +169,7 @@ void launch_scatter_units(hipStream_t, const void *, void *, const PassGeom &, c
 void launch_diff_hist(hipStream_t, const u64 *, u64, u64 *) {}
 void launch_check_radix(hipStream_t, const void *, const u64 *, const void *, const u64 *, u64, int, u64 *) {}
 void launch_prefix(hipStream_t, const u64 *, u64, u64 *) {}
-void launch_make_tasks(hipStream_t st, const u64 *, const u64 *, u64, u32, JoinTask *, u32 *d_ntasks, u32, u64 *, int)
+void launch_make_tasks(hipStream_t st, const u64 *, const u64 *, u64, u32, JoinTask *, u32 *d_ntasks, u32, u64 *, int, const SniffVerdict &)
 {
     fake_enqueue(st, [=] { *d_ntasks = 1; });
 }
@@ -195,7 +195,7 @@ void launch_join(hipStream_t st, const void *, const u64 *, const void *, const 
 }
 size_t fuse_ctl_bytes() { return 12352; }
 u32 *fuse_join_ticket(void *d_ctl) { return (u32 *)((unsigned char *)d_ctl + 12288) + 1; }
-void launch_fused_pass(hipStream_t st, const PassPairHost &, int, int phase, int, void *, u32, u32, u32, JoinTask *, u64 *d_counters, u64 *)
+void launch_fused_pass(hipStream_t st, const PassPairHost &, int, int phase, int, void *, u32, u32, u32, JoinTask *, u64 *d_counters, u64 *, bool)
 {
     if (phase == 0) fake_enqueue(st, [=] { memset(d_counters, 0, 64); });           // (the histogram launch clears the join counters)
 }
@@ -223,7 +223,7 @@ void launch_pass_pair(hipStream_t st, const PassPairHost &h, int, int, int phase
     u64 *z = h.zero8;
     if (phase == 0 && z) fake_enqueue(st, [=] { memset(z, 0, 64); });      // (the first launch clears the join counters)
 }
-void launch_hist2d_units(hipStream_t, const void *, bool, u64, u64, u32, int, int, u32, u32, u32 *, u32 *, u64, u32 *, const u64 *, int) {}
+void launch_hist2d_units(hipStream_t, const void *, bool, u64, u64, u32, int, int, u32, u32, u32 *, u32 *, u64, u32 *, const u64 *, int, const DupSniff &) {}
 void launch_seg_units(hipStream_t, u32, const u64 *, const u64 *, u32, u64 *, u64 *, u32 *) {}
 void launch_make_group_ranges(hipStream_t, const u64 *, u32, u32, u32, u64, u64 *, u32 *) {}
 void launch_scatter_ranges(hipStream_t, const void *, void *, u32, int, int, const u64 *, const u64 *) {}

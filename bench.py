@@ -395,6 +395,19 @@ def extras(eng, torch, dev, steps, which="all"):
             cnt, sec = timed_join(R, S, n, out, opts, steps)
             res["c4_1Bx1B_zipf0.9"][name] = {"ms": sec * 1e3, "tuples_per_s": 2 * n / sec,
                                              "verified": (cnt, eng.pairs_checksum(out, cnt)) == exp}
+        # the headline workload with the arguments EXCHANGED (foreign-key relation first), and what the choice of the build side
+        # is worth: where a partition's two sides are within 1/16 of each other the engine builds the hash table on the side
+        # whose sampled join values show fewer duplicates ("join.sniff", include/rhj.h) -- so the order of the arguments does
+        # not matter; with the sampling off the FIRST argument wins such ties (fast for R JOIN S, slow for S JOIN R).
+        eng.generate(GEN_S_UNIFORM, S, n, D=n, seed=42)
+        exp_n, _ = eng.expected_pkfk(S, n)
+        leg = {}
+        for name, sniff, A, B in (("R_join_S", -1, R, S), ("S_join_R", -1, S, R), ("S_join_R_sampling_off", 0, S, R)):
+            eng.set_option("join.sniff", sniff)
+            cnt, sec = timed_join(A, B, n, out, rhj.Opts(2, 8, 8), steps)
+            leg[name] = {"ms": sec * 1e3, "tuples_per_s": 2 * n / sec, "count_ok": cnt == exp_n}
+        eng.set_option("join.sniff", -1)
+        res["build_side_1Bx1B_uniform"] = leg
         del R, S, out
     eng.release_workspace()
     torch.cuda.empty_cache()

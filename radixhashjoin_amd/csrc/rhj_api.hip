@@ -825,9 +825,17 @@ int partition_relation_narrow2(rhj_ctx *ctx, const void *d_in, u64 n, int b1, in
             if (!pass) launch_init_single_segment(ctx->stream, n, g.L, (u64 *)ctx->seg0.p, unit_start);
             else launch_make_units(ctx->stream, seg_start, nseg, g.L, unit_start);
         }
+        DupSniff sn;
+        if (!pass && !d_inK && ctx->sniff_side >= 0) {  // a join's relation: sample its join values for duplicates
+            sn.tab = (u32 *)ctx->sniff_tab.p + (size_t)ctx->sniff_side * SNIFF_SLOTS;
+            sn.sel_bits = sniff_sel_bits(n);
+            ctx->sniff_n[ctx->sniff_side] = n;
+            Span s(ctx, RHJ_K_AUX);
+            HIPCHK(ctx, hipMemsetAsync(sn.tab, 0, (size_t)SNIFF_SLOTS * 4, ctx->stream));
+        }
         {
             Span s(ctx, RHJ_K_HIST);
-            if (!pass && !d_inK) launch_hist_units(ctx->stream, d_in, g, seg_start, unit_start, (u32 *)ctx->unit_hist.p);
+            if (!pass && !d_inK) launch_hist_units(ctx->stream, d_in, g, seg_start, unit_start, (u32 *)ctx->unit_hist.p, nullptr, sn);
             else launch_hist_units_narrow(ctx->stream, pass ? ctx->part_tmp.p : d_in, g, seg_start, unit_start, (u32 *)ctx->unit_hist.p);
         }
         {
@@ -1014,9 +1022,17 @@ int partition_phase(rhj_ctx *ctx, const void *d_R, u64 nR, const void *d_S, u64 
         RHJCHK(ensure(ctx, ctx->part_R, (size_t)(nR ? nR : 1) * 16));
         RHJCHK(ensure(ctx, ctx->part_S, (size_t)(nS ? nS : 1) * 16));
         if (ctx->cur_narrow && !narrow_fused_plan(plan)) {
-            RHJCHK(partition_relation_narrow2(ctx, d_R, nR, plan.bits1, plan.bits2, ctx->part_R.p, (u64 *)ctx->ps_R.p, nullptr, mix));
-            RHJCHK(s_ready());
-            RHJCHK(partition_relation_narrow2(ctx, d_S, nS, plan.bits1, plan.bits2, ctx->part_S.p, (u64 *)ctx->ps_S.p, nullptr, mix));
+            const bool sniff = sniff_on(ctx);
+            if (sniff) RHJCHK(ensure(ctx, ctx->sniff_tab, (size_t)2 * SNIFF_SLOTS * 4));
+            ctx->sniff_side = sniff ? 0 : -1;
+            int prc = partition_relation_narrow2(ctx, d_R, nR, plan.bits1, plan.bits2, ctx->part_R.p, (u64 *)ctx->ps_R.p, nullptr, mix);
+            if (prc == RHJ_OK) prc = s_ready();
+            ctx->sniff_side = sniff ? 1 : -1;
+            if (prc == RHJ_OK)
+                prc = partition_relation_narrow2(ctx, d_S, nS, plan.bits1, plan.bits2, ctx->part_S.p, (u64 *)ctx->ps_S.p, nullptr, mix);
+            ctx->sniff_side = -1;
+            RHJCHK(prc);
+            ctx->sniff_ready = sniff;
         } else if (two_streams_ok(ctx, nR, nS, plan, before_S)) {
             // Mid-size joins are launch-bound (a fused two-pass partition is ~11 short dependent launches per relation): R and S
             // are independent until the join, so S is partitioned on a second stream, in a second set of scratch tables, while R

@@ -66,14 +66,6 @@ constexpr int MIX_NONE = 0, MIX_STORE = 1, MIX_DIGIT = 2;
 
 // launchers (all asynchronous on `st`)
 void launch_init_single_segment(hipStream_t st, u64 n, u64 L, u64 *d_seg_start, u32 *d_unit_start);
-void launch_make_units(hipStream_t st, const u64 *d_seg_start, u32 nseg, u64 L, u32 *d_unit_start);
-// d_minmax (may be null): two u64, atomicMin / atomicMax of the rowIDs seen
-void launch_hist_units(hipStream_t st, const void *d_in, const PassGeom &g, const u64 *d_seg_start,
-                       const u32 *d_unit_start, u32 *d_unit_hist, u64 *d_minmax = nullptr);
-void launch_scan_units(hipStream_t st, const PassGeom &g, const u64 *d_seg_start, const u32 *d_unit_start,
-                       const u32 *d_unit_hist, u64 *d_unit_base, u64 *d_part_start, u64 *d_scan_tmp);
-void launch_scatter_units(hipStream_t st, const void *d_in, void *d_out, const PassGeom &g,
-                          const u64 *d_seg_start, const u32 *d_unit_start, const u64 *d_unit_base);
 // DupSniff: which side of a join has duplicate join values -- asked of the data, by the histogram kernels that read every tuple
 // anyway.  A tuple whose mix64(payload) has sel_bits leading zero bits is SAMPLED (a fixed subset of the VALUES, so every
 // duplicate of a sampled value is sampled too; sel_bits such that 256-512 tuples of the relation are) and counted in one of
@@ -86,6 +78,14 @@ constexpr u32 SNIFF_SLOTS = 16384, SNIFF_TARGET = 512;
 struct DupSniff { u32 *tab = nullptr; int sel_bits = 0; };
 struct SniffVerdict { const u32 *tab = nullptr; u32 expect_R = 0, expect_S = 0; };   // tab: [2 sides][SNIFF_SLOTS]; expected samples
 inline int sniff_sel_bits(u64 n) { int s = 0; while ((n >> s) > SNIFF_TARGET) s++; return s; }
+void launch_make_units(hipStream_t st, const u64 *d_seg_start, u32 nseg, u64 L, u32 *d_unit_start);
+// d_minmax (may be null): two u64, atomicMin / atomicMax of the rowIDs seen
+void launch_hist_units(hipStream_t st, const void *d_in, const PassGeom &g, const u64 *d_seg_start,
+                       const u32 *d_unit_start, u32 *d_unit_hist, u64 *d_minmax = nullptr, const DupSniff &sniff = DupSniff());
+void launch_scan_units(hipStream_t st, const PassGeom &g, const u64 *d_seg_start, const u32 *d_unit_start,
+                       const u32 *d_unit_hist, u64 *d_unit_base, u64 *d_part_start, u64 *d_scan_tmp);
+void launch_scatter_units(hipStream_t st, const void *d_in, void *d_out, const PassGeom &g,
+                          const u64 *d_seg_start, const u32 *d_unit_start, const u64 *d_unit_base);
 void launch_diff_hist(hipStream_t st, const u64 *d_start, u64 nbins, u64 *d_hist);
 void launch_check_radix(hipStream_t st, const void *d_R, const u64 *d_startR, const void *d_S, const u64 *d_startS, u64 nparts,
                         int radix_bits, u64 *d_bad);

@@ -222,10 +222,17 @@ k_hist_units_n(const u64 *__restrict__ inP, const u64 *__restrict__ seg_start, c
     for (u32 b = threadIdx.x; b < nbins; b += PART_THREADS) out[b] = cnt[b];
 }
 
+// DupSniff (rhj_internal.h): m = mix64(payload)
+__device__ __forceinline__ void sniff_sample(const DupSniff &sn, u64 m)
+{
+    if (sn.sel_bits > 0 && (m >> (64 - sn.sel_bits)) != 0) return;
+    const u64 m2 = mix64(m ^ 0xA5A5A5A5A5A5A5A5ull);             // (bits of its own for the slot: the sampled values share their top bits)
+    (void)__hip_atomic_fetch_add(&sn.tab[(u32)m2 & (SNIFF_SLOTS - 1)], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
 __device__ __forceinline__ void
 dev_hist_units(const Tup *__restrict__ in, const u64 *__restrict__ seg_start, const u32 *__restrict__ unit_start,
                u32 nseg, u64 L, int shift, int bits, u32 *__restrict__ unit_hist, const u32 u, u64 *__restrict__ minmax = nullptr,
-               int mix = 0)
+               int mix = 0, const DupSniff sn = DupSniff())
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     u32 *cnt = reinterpret_cast<u32 *>(smem);
@@ -242,7 +249,11 @@ dev_hist_units(const Tup *__restrict__ in, const u64 *__restrict__ seg_start, co
     u64 i = beg + threadIdx.x;
     u64 kmin = ~0ull, kmax = 0;                        // range of the rowIDs (minmax != nullptr: the multi-GPU sender's class histogram)
     // mix != 0: the digit comes from mix64(payload) (inside a join, see MIX_* in rhj_internal.h)
-    auto dig = [&](u64 p) -> u32 { return (u32)((mix ? mix64(p) : p) >> shift) & mask; };
+    auto dig = [&](u64 p) -> u32 {
+        const u64 m = mix ? mix64(p) : p;
+        if (sn.tab != nullptr) sniff_sample(sn, mix ? m : mix64(p));
+        return (u32)(m >> shift) & mask;
+    };
     // 4 independent 16 B loads in flight per lane
     for (; i + 3ull * PART_THREADS < end; i += 4ull * PART_THREADS) {
         const Tup t0 = in[i], t1 = in[i + PART_THREADS], t2 = in[i + 2 * PART_THREADS], t3 = in[i + 3 * PART_THREADS];
@@ -280,9 +291,9 @@ dev_hist_units(const Tup *__restrict__ in, const u64 *__restrict__ seg_start, co
 
 __global__ void __launch_bounds__(PART_THREADS)
 k_hist_units(const Tup *__restrict__ in, const u64 *__restrict__ seg_start, const u32 *__restrict__ unit_start,
-             u32 nseg, u64 L, int shift, int bits, u32 *__restrict__ unit_hist, u64 *__restrict__ minmax, int mix)
+             u32 nseg, u64 L, int shift, int bits, u32 *__restrict__ unit_hist, u64 *__restrict__ minmax, int mix, DupSniff sn)
 {
-    dev_hist_units(in, seg_start, unit_start, nseg, L, shift, bits, unit_hist, blockIdx.x, minmax, mix);
+    dev_hist_units(in, seg_start, unit_start, nseg, L, shift, bits, unit_hist, blockIdx.x, minmax, mix, sn);
 }
 
 __global__ void __launch_bounds__(PART_THREADS) k_hist_units2(PassPair a, int shift, int bits)
@@ -311,13 +322,6 @@ constexpr int H2_THREADS = 1024;
 // pass-2 unit, holds tuples of ONE sender).  Null: unit u = rows [u * L, (u+1) * L).  Group = u / units_per_group either way.
 
 // IN_NARROW: the input is a payload array (8 B/tuple; a received narrow shard), no rowIDs to inspect.
-// DupSniff (rhj_internal.h): m = mix64(payload)
-__device__ __forceinline__ void sniff_sample(const DupSniff &sn, u64 m)
-{
-    if (sn.sel_bits > 0 && (m >> (64 - sn.sel_bits)) != 0) return;
-    const u64 m2 = mix64(m ^ 0xA5A5A5A5A5A5A5A5ull);             // (bits of its own for the slot: the sampled values share their top bits)
-    (void)__hip_atomic_fetch_add(&sn.tab[(u32)m2 & (SNIFF_SLOTS - 1)], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
 // the planners' question: does R have no more duplicates (per sampled tuple) than S?  Called by EVERY thread of the workgroup
 // (barriers inside); sh: two words of LDS.
 __device__ __forceinline__ bool sniff_prefers_R(const SniffVerdict &sv, u32 *sh)
@@ -2806,11 +2810,11 @@ void launch_make_units(hipStream_t st, const u64 *d_seg_start, u32 nseg, u64 L, 
 }
 
 void launch_hist_units(hipStream_t st, const void *d_in, const PassGeom &g, const u64 *d_seg_start,
-                       const u32 *d_unit_start, u32 *d_unit_hist, u64 *d_minmax)
+                       const u32 *d_unit_start, u32 *d_unit_hist, u64 *d_minmax, const DupSniff &sniff)
 {
     if (g.max_units == 0) return;
     hipLaunchKernelGGL(k_hist_units, dim3(g.max_units), dim3(PART_THREADS), ((size_t)4 << g.bits), st,
-                       (const Tup *)d_in, d_seg_start, d_unit_start, g.nseg, g.L, g.shift, g.bits, d_unit_hist, d_minmax, g.mix);
+                       (const Tup *)d_in, d_seg_start, d_unit_start, g.nseg, g.L, g.shift, g.bits, d_unit_hist, d_minmax, g.mix, sniff);
 }
 
 void launch_hist_units_narrow(hipStream_t st, const void *d_inP, const PassGeom &g, const u64 *d_seg_start,

@@ -163,7 +163,7 @@ size_t part_lds_bytes(int) { return 0; }
 
 void launch_init_single_segment(hipStream_t, u64, u64, u64 *, u32 *) {}
 void launch_make_units(hipStream_t, const u64 *, u32, u64, u32 *) {}
-void launch_hist_units(hipStream_t, const void *, const PassGeom &, const u64 *, const u32 *, u32 *, u64 *) {}
+void launch_hist_units(hipStream_t, const void *, const PassGeom &, const u64 *, const u32 *, u32 *, u64 *, const DupSniff &) {}
 void launch_scan_units(hipStream_t, const PassGeom &, const u64 *, const u32 *, const u32 *, u64 *, u64 *, u64 *) {}
 void launch_scatter_units(hipStream_t, const void *, void *, const PassGeom &, const u64 *, const u32 *, const u64 *) {}
 void launch_diff_hist(hipStream_t, const u64 *, u64, u64 *) {}

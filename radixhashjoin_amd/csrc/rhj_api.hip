@@ -200,6 +200,7 @@ struct rhj_ctx {
     int sniff_side = -1;               // partition_relation_fused: the side it is counting for (-1: no sampling)
     u64 sniff_n[2] = {0, 0};
     bool sniff_ready = false;          // both sides of the current join were sampled: k_make_tasks may ask
+    bool shard_sniffed[2] = {false, false};   // rhj_shard_partition sampled this side's received join values
     u64 *h_pub = nullptr, *h_pub_dev = nullptr;   // pinned: the join counters as the bucket join's last workgroup publishes them
     int opt_fused = -1;                // -1: automatic (RHJ_FUSE env, default 1), 0 / 1
     int opt_sniff = -1;                // -1: automatic (RHJ_SNIFF env, default 1), 0 / 1: sample the join values for duplicates (DupSniff)
@@ -731,7 +732,7 @@ int partition_relation_fused(rhj_ctx *ctx, const FusedIn &in, u64 n, int b1, int
         HIPCHK(ctx, hipMemsetAsync(x_hist2.p, 0, (size_t)units2 * nb2 * 4, st));
     }
     DupSniff sn;
-    if (ctx->sniff_side >= 0 && !segs) {                // a join's relation: sample its join values for duplicates
+    if (ctx->sniff_side >= 0) {                         // a join's relation: sample its join values for duplicates
         const int side = ctx->sniff_side;
         sn.tab = (u32 *)ctx->sniff_tab.p + (size_t)side * SNIFF_SLOTS;
         sn.sel_bits = sniff_sel_bits(n);
@@ -2569,6 +2570,7 @@ int rhj_shard_partition(rhj_ctx *ctx, int side, const uint64_t *d_payloads, cons
     RHJCHK(ensure(ctx, ctx->tag_base, 2 * sizeof(bases)));
     u64 *d_bases = (u64 *)ctx->tag_base.p + 16 * side;
     HIPCHK(ctx, hipMemcpyAsync(d_bases, bases, sizeof(bases), hipMemcpyHostToDevice, ctx->stream));   // (pageable source: staged before the call returns)
+    ctx->shard_sniffed[side] = false;
     if (m == 0) {                                       // nothing arrived: all boundaries 0
         HIPCHK(ctx, hipMemsetAsync(ps.p, 0, (np + 1) * 8, ctx->stream));
     } else {
@@ -2579,7 +2581,15 @@ int rhj_shard_partition(rhj_ctx *ctx, int side, const uint64_t *d_payloads, cons
         in.seg_off = (const u64 *)seg_off;
         in.final_form = mode == RHJ_SHARD_TAGGED ? 1 : mode == RHJ_SHARD_GLOBAL16 ? 2 : 0;
         in.key_bases = d_bases;
-        if (fused) RHJCHK(partition_relation_fused(ctx, in, m, plan->bits1, plan->bits2, part.p, (u64 *)ps.p, 2));
+        if (fused) {
+            const bool sniff = sniff_on(ctx);                                   // (the received join values are sampled for duplicates too)
+            if (sniff) RHJCHK(ensure(ctx, ctx->sniff_tab, (size_t)2 * SNIFF_SLOTS * 4));
+            ctx->sniff_side = sniff ? side : -1;
+            const int prc = partition_relation_fused(ctx, in, m, plan->bits1, plan->bits2, part.p, (u64 *)ps.p, 2);
+            ctx->sniff_side = -1;
+            RHJCHK(prc);
+            ctx->shard_sniffed[side] = sniff;
+        }
         else RHJCHK(partition_relation_narrow2(ctx, d_payloads, m, plan->bits1, plan->bits2, part.p, (u64 *)ps.p, (const u32 *)d_rowids));
     }
     ctx->shard_side_done[side] = true;
@@ -2606,6 +2616,7 @@ int rhj_shard_join(rhj_ctx *ctx, rhj_pair *d_out, uint64_t out_capacity, uint64_
     if (mode == RHJ_SHARD_TAGGED && choose_join_kind(ctx, mR, mS, (u64)1 << tb, tb, false, false) != JK_BKT)
         return fail(ctx, RHJ_E_INVALID, "rhj_shard_join: partitions this large need RHJ_SHARD_GLOBAL16 (see rhj_shard_plan)");
     ctx->cur_narrow = narrow ? 2 : 0;
+    ctx->sniff_ready = ctx->shard_sniffed[0] && ctx->shard_sniffed[1];
     ctx->last.passes = 2;
     ctx->last.bits1 = ctx->shard_plan.bits1;
     ctx->last.bits2 = ctx->shard_plan.bits2;

@@ -389,7 +389,7 @@ k_hist2d_units(const Tup *__restrict__ in, const u64 *__restrict__ inP, u64 n, u
 
     auto count = [&](u64 payload) {
         if (!IN_NARROW && mix) payload = mix64(payload);      // (16-byte input inside a join: digits of the mixed payload)
-        if (!IN_NARROW && sn.tab != nullptr) sniff_sample(sn, mix ? payload : mix64(payload));
+        if (sn.tab != nullptr) sniff_sample(sn, IN_NARROW || mix ? payload : mix64(payload));   // (received payloads are mixed already)
         const u32 d1 = (u32)payload & m1, d2 = (u32)(payload >> b1) & m2;
         const u32 bin = (d1 << b2) | d2, sh = (bin & 1u) * 16u;
         const u32 old = atomicAdd(&tab[bin >> 1], 1u << sh);
@@ -2993,7 +2993,7 @@ void launch_hist2d_units(hipStream_t st, const void *d_in, bool in_narrow, u64 n
     if (units == 0) return;
     if (in_narrow)
         hipLaunchKernelGGL(k_hist2d_units<true>, dim3(units), dim3(H2_THREADS), lds, st, (const Tup *)nullptr, (const u64 *)d_in, n,
-                           L, b1, b2, units_per_group, ngroups, d_hist1, d_hist2, (u64)0, (u32 *)nullptr, d_unit_rng, 0, DupSniff());
+                           L, b1, b2, units_per_group, ngroups, d_hist1, d_hist2, (u64)0, (u32 *)nullptr, d_unit_rng, 0, sniff);
     else
         hipLaunchKernelGGL(k_hist2d_units<false>, dim3(units), dim3(H2_THREADS), lds, st, (const Tup *)d_in, (const u64 *)nullptr, n,
                            L, b1, b2, units_per_group, ngroups, d_hist1, d_hist2, key_base, d_wide, d_unit_rng, mix, sniff);

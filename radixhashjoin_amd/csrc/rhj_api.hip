@@ -463,6 +463,15 @@ int ilog2_ceil(u64 x)
 // Reference: one fixed 8-bit pass (Result.cpp:5,91).  Here: the fewest radix bits such that the
 // average build-side partition fills at most 15/16 of one LDS hash table (BJ_CHUNK), in <= 2 passes.
 // device_resident: the inputs are in HBM already (rhj_join_dev); else the host-pointer call, whose small path is one launch
+// largest average partition (tuples, either side) the 6144-entry kernel with 13-bit arrival indices is chosen for
+u64 g13_upto()
+{
+    // 15/16 of its table: the row guards stop paying beyond CT_GUARDED_UPTO, but half as many partitions still do ([measured, wall
+    // ms, 5120 -> 5760] 43M 1.852 -> 1.760 . 46M 1.894 -> 1.710 . 86M 3.364 -> 3.164 . 93M 3.459 -> 3.363 . 170M 6.732 -> 6.097 . 185M 7.082 -> 6.297)
+    static const u64 v = env_u64("RHJ_G13_UPTO", (u64)join_table_tuples(JK_CT_G13) * 15 / 16, 2048, 5760);      // tuning aid
+    return v;
+}
+
 bool default_join_kernels(const rhj_ctx *ctx) { return ctx->opt_big_kernel < 0 && ctx->opt_big_tables < 0; }
 
 // ct13_ok: the join may pick the 6144-entry compact-table kernel for plans of 13-15 bits (default kernel choice, not the
@@ -505,12 +514,12 @@ int resolve_plan(u64 nR, u64 nS, const rhj_opts *in, rhj_opts *out, bool device_
                 // <GR = 16>) and a second, 8 B/tuple histogram read of the narrow intermediate.
                 if (bits > 16) bits = nb <= (u64)65536 * 16800 ? 16 : nb <= (u64)131072 * 16800 ? 17 : 18;
                 // One bit fewer where that leaves partitions for the 6144-entry compact-table kernel (k_join_ct<.., KB = 13>, plans
-                // of 13-15 bits, average partitions of up to CT_GUARDED_UPTO tuples on both sides): half as many partitions,
+                // of 13-15 bits, average partitions of up to 15/16 of its 6144 entries on both sides): half as many partitions,
                 // tasks and histogram rows.  [measured, one box, wall ms, bits as above -> one fewer] 34M 1.538 -> 1.431 . 40M 1.722 ->
                 // 1.579 . 66M 2.814 -> 2.538 . 83M 3.397 -> 2.971 . 135M 5.692 -> 5.091 . 165M 6.729 -> 6.084
                 static const bool ct13_env = env_u64("RHJ_CT13", 1, 0, 1) != 0;
                 if (ct13_ok && ct13_env && bits - 1 >= join_ct_min_radix_bits(JK_CT_G13) && bits - 1 < join_ct_min_radix_bits(JK_CT) &&
-                    (nb >> (bits - 1)) <= (u64)CT_GUARDED_UPTO && (np_ >> (bits - 1)) <= (u64)CT_GUARDED_UPTO)
+                    (nb >> (bits - 1)) <= g13_upto() && (np_ >> (bits - 1)) <= g13_upto())
                     bits -= 1;
                 o.passes = 2; o.bits1 = (bits + 1) / 2; o.bits2 = bits / 2;
                 // 17 bits: the 9-bit pass second -- from the narrow intermediate it costs 5.3 ms per 10^9 tuples, from 16-byte
@@ -894,7 +903,7 @@ int choose_join_kind(const rhj_ctx *ctx, u64 nR, u64 nS, u64 nparts, int radix_b
         static const bool on = env_u64("RHJ_CT13", 1, 0, 1) != 0;              // tuning aid: 0 = the one-table kernel as before
         const u64 nprobe13 = nR < nS ? nS : nR, ab13 = nbuild / nparts, ap13 = nprobe13 / nparts;
         const bool fits13 = ab13 <= (u64)join_table_tuples(JK_CT_G13) * 15 / 16 && ap13 <= (u64)join_probe_split(JK_CT_G13) * 15 / 16 &&
-                            ab13 <= (u64)CT_GUARDED_UPTO && ap13 <= (u64)CT_GUARDED_UPTO;
+                            ab13 <= g13_upto() && ap13 <= g13_upto();
         if ((ctx->opt_big_kernel == JK_CT_G13 && ctx->opt_big_tables == 1) ||
             (on && ctx->opt_big_tables < 0 && ab13 > (u64)CT_GUARDED_FROM && fits13))
             return JK_CT_G13;

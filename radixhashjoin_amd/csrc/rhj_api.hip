@@ -2109,7 +2109,7 @@ int batch_stage(rhj_ctx *ctx, int sl, BatchSlot &b, const rhj_join_desc *J, cons
         d.cap = b.dcap[i];
         d.count = (u64 *)((unsigned char *)ctx->b_cnt[sl].p + (size_t)i * 16);
         d.done = (u32 *)((unsigned char *)ctx->b_cnt[sl].p + (size_t)i * 16 + 8);
-        d.build_is_S = j.nR >= j.nS ? 1u : 0u;              // JobScheduler.cpp:187
+        d.build_is_S = j.nR >= j.nS + (j.nS >> build_tie_shift()) ? 1u : 0u;      // JobScheduler.cpp:187, near ties: R (build_on_S)
         d.nb = (u32)(d.build_is_S ? j.nS : j.nR);
         d.np = (u32)(d.build_is_S ? j.nR : j.nS);
         d.split = tile;

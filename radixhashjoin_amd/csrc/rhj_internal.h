@@ -78,6 +78,7 @@ constexpr u32 SNIFF_SLOTS = 16384, SNIFF_TARGET = 512;
 struct DupSniff { u32 *tab = nullptr; int sel_bits = 0; };
 struct SniffVerdict { const u32 *tab = nullptr; u32 expect_R = 0, expect_S = 0; };   // tab: [2 sides][SNIFF_SLOTS]; expected samples
 inline int sniff_sel_bits(u64 n) { int s = 0; while ((n >> s) > SNIFF_TARGET) s++; return s; }
+int build_tie_shift();                             // sizes within 1/2^this of each other are a tie (RHJ_BUILD_TIE, default 4: 1/16)
 void launch_make_units(hipStream_t st, const u64 *d_seg_start, u32 nseg, u64 L, u32 *d_unit_start);
 // d_minmax (may be null): two u64, atomicMin / atomicMax of the rowIDs seen
 void launch_hist_units(hipStream_t st, const void *d_in, const PassGeom &g, const u64 *d_seg_start,

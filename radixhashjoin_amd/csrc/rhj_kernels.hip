@@ -1037,11 +1037,6 @@ __device__ __forceinline__ bool build_on_S(u64 nr, u64 ns, int tie_shift, bool p
 {
     return prefer_R ? nr >= ns + (ns >> tie_shift) : nr + (nr >> tie_shift) >= ns;
 }
-int build_tie_shift()
-{
-    static const int v = getenv("RHJ_BUILD_TIE") ? atoi(getenv("RHJ_BUILD_TIE")) : 4;      // tuning aid: 63 = the reference's rule exactly
-    return v < 1 ? 1 : v > 63 ? 63 : v;
-}
 
 // ---- one-pass joins in THREE launches (mid-size joins are launch-bound: 10^6 x 10^6 was 8 dependent launches for 77 us of
 // kernel time) ------------------------------------------------------------------------------------------------------------
@@ -2681,6 +2676,13 @@ k_generate(int kind, Tup *__restrict__ out, u64 n, u64 row0, u64 D, u64 seed, do
 // ------------------------------------------------------------------------------------------------
 size_t scan_tmp_bytes(int bits) { return (size_t)SCAN_SLICES * ((size_t)8 << bits); }
 
+// sizes within 1/2^this of each other are a tie when a partition's build side is chosen (build_on_S)
+int build_tie_shift()
+{
+    static const int v = getenv("RHJ_BUILD_TIE") ? atoi(getenv("RHJ_BUILD_TIE")) : 4;      // tuning aid: 63 = the reference's rule exactly
+    return v < 1 ? 1 : v > 63 ? 63 : v;
+}
+
 size_t part_lds_bytes(int bits)
 {
     const size_t nbins = (size_t)1 << bits;
@@ -3312,7 +3314,7 @@ void launch_join_direct(hipStream_t st, const void *d_R, u64 nR, const void *d_S
     dj.done = d_done;
     dj.host_out = (Pair *)host_out;
     dj.host_cap = host_out ? host_cap : 0;
-    dj.build_is_S = nR >= nS ? 1u : 0u;
+    dj.build_is_S = nR >= nS + (nS >> build_tie_shift()) ? 1u : 0u;      // (the smaller side; near ties: R -- see build_on_S)
     dj.nb = (u32)(dj.build_is_S ? nS : nR);
     dj.np = (u32)(dj.build_is_S ? nR : nS);
     dj.split = (u32)BJ_TILE;

@@ -193,6 +193,7 @@ void launch_join(hipStream_t st, const void *, const u64 *, const void *, const 
         if (host_pub) for (int i = 0; i < 7; i++) host_pub[i] = d_out_count[i];      // (the last workgroup publishes the counters)
     });
 }
+int build_tie_shift() { return 4; }
 size_t fuse_ctl_bytes() { return 12352; }
 u32 *fuse_join_ticket(void *d_ctl) { return (u32 *)((unsigned char *)d_ctl + 12288) + 1; }
 void launch_fused_pass(hipStream_t st, const PassPairHost &, int, int phase, int, void *, u32, u32, u32, JoinTask *, u64 *d_counters, u64 *, bool)

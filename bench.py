@@ -530,7 +530,7 @@ def main():
 
     for _ in range(args.warmup):
         step()
-    eng.set_profiling(True)
+    eng.set_profiling(2)                               # HIP events around every launch; read ONCE, after the timed steps
     if world > 1:
         sj.kernel_ms = {}
     kt = {"hist": [0.0, 0], "scan": [0.0, 0], "scatter": [0.0, 0], "tasks": [0.0, 0], "join": [0.0, 0], "aux": [0.0, 0]}
@@ -540,18 +540,19 @@ def main():
     cnt, res = 0, None
     for _ in range(args.steps):
         cnt, res = step()
-        if world == 1:
-            t = eng.timings()                          # HIP events recorded around every launch of this step
-            for k in kt:
-                kt[k][0] += t[k]["ms"]
-                kt[k][1] += t[k]["launches"]
-            sc = [ms for kind, ms in eng.launch_timings() if kind == "scatter"]
-            if args.passes == 2 and len(sc) == 4:
-                for i, ms in enumerate(sc):
-                    sc_pass[1 + (i & 1)][0] += ms
-                    sc_pass[1 + (i & 1)][1] += 1
     barrier()
     dt = time.perf_counter() - t0
+    if world == 1:
+        lt = eng.launch_timings()                      # every launch of the timed steps, in launch order
+        for kind, ms in lt:
+            if kind in kt:
+                kt[kind][0] += ms
+                kt[kind][1] += 1
+        sc = [ms for kind, ms in lt if kind == "scatter"]
+        if args.passes == 2 and len(sc) == 4 * args.steps:       # per step: R pass 1, R pass 2, S pass 1, S pass 2
+            for i, ms in enumerate(sc):
+                sc_pass[1 + (i & 1)][0] += ms
+                sc_pass[1 + (i & 1)][1] += 1
     if world > 1:
         # per-kernel device time of the sharded path: `steps` MORE steps, outside the timed region (reading the HIP events of
         # an engine call synchronises after it, which the timed steps must not do)

@@ -101,6 +101,9 @@ void rhj_destroy(rhj_ctx *ctx);
 const char *rhj_last_error(const rhj_ctx *ctx);          /* ctx may be NULL: last global error */
 /* run on a caller-owned hipStream_t (e.g. torch's current stream); NULL = context's own stream */
 int  rhj_set_stream(rhj_ctx *ctx, void *hip_stream);
+/* enabled: 0 off; 1 every launch of a call is timed with a HIP event pair (rhj_get_timings / rhj_get_launch_timings report the
+ * LAST call); 2 the same, and the launches of successive calls ACCUMULATE until profiling is set again (a benchmark reads the
+ * events once, after its timed loop, instead of after every step) */
 int  rhj_set_profiling(rhj_ctx *ctx, int enabled);
 /* tuning / test knobs; results never depend on them.  "join.big_tables": -1 (default) choose the bucket-join kernel by
  * the average build partition, 0 always the one-table kernel, 1 always an oversized-partition kernel;

@@ -283,14 +283,15 @@ class Engine:
         return v.value
 
     def set_profiling(self, on=True):
-        self._chk(self.lib.rhj_set_profiling(self.ctx, 1 if on else 0))
+        """True / 1: time every launch of a call; 2: accumulate the launches of successive calls (see rhj.h); False / 0: off"""
+        self._chk(self.lib.rhj_set_profiling(self.ctx, 2 if on == 2 and on is not True else 1 if on else 0))
 
     def timings(self):
         t = Timings()
         self._chk(self.lib.rhj_get_timings(self.ctx, C.byref(t)))
         return t.as_dict()
 
-    def launch_timings(self, capacity=256):
+    def launch_timings(self, capacity=4096):
         """[(kind name, ms)] of every timed launch span of the last call, in launch order (profiling must be on)"""
         kinds, ms, n = (_i32 * capacity)(), (C.c_double * capacity)(), C.c_uint32()
         self._chk(self.lib.rhj_get_launch_timings(self.ctx, kinds, ms, capacity, C.byref(n)))

@@ -30,6 +30,7 @@ struct DevBuf {
 
 struct Prof {
     bool on = false;
+    bool keep = false;                     // rhj_set_profiling(ctx, 2): the spans of successive calls accumulate
     std::vector<hipEvent_t> pool;          // event pairs, reused
     std::vector<int> kinds;                // kind per recorded pair
     size_t used = 0;
@@ -420,8 +421,10 @@ struct Span {
 
 void prof_reset(rhj_ctx *ctx)
 {
-    ctx->prof.used = 0;
-    ctx->prof.kinds.clear();
+    if (!ctx->prof.keep) {
+        ctx->prof.used = 0;
+        ctx->prof.kinds.clear();
+    }
     memset(&ctx->last, 0, sizeof(ctx->last));
 }
 
@@ -1528,7 +1531,9 @@ int rhj_set_profiling(rhj_ctx *ctx, int enabled)
 {
     if (!ctx) return RHJ_E_INVALID;
     ctx->prof.on = enabled != 0;
-    prof_reset(ctx);
+    ctx->prof.keep = false;
+    prof_reset(ctx);                       // (also the start of an accumulating series)
+    ctx->prof.keep = enabled == 2;
     return RHJ_OK;
 }
 

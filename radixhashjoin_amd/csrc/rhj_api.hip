@@ -192,7 +192,7 @@ struct rhj_ctx {
     size_t b_land_cap[2] = {0, 0};
     DevBuf b_in[2], b_out[2], b_cnt[2];   // device: staged blob, pair buffers, per-join {count, ticket}
     hipEvent_t b_ev[2] = {nullptr, nullptr};
-    DevBuf fuse_ctl;                   // one-pass joins in three launches: global histograms, digit cursors, tickets (k_hist_fused2)
+    DevBuf fuse_ctl;                   // one-pass joins in three launches: two copies of {global histograms, digit cursors, sample counters} + the join's ticket
     bool fuse_clean = false;           // ... whose copy for the next call the kernels leave zeroed (false: the next call clears both first)
     int fuse_parity = 0;               // the copy the next call uses
     // which side of a join has duplicate join values (DupSniff, rhj_internal.h): the sample counters of R and S for a two-pass join
@@ -499,11 +499,10 @@ int resolve_plan(u64 nR, u64 nS, const rhj_opts *in, rhj_opts *out, bool device_
             if (nb > (u64)BJ_CHUNK && !direct) bits = ilog2_ceil((nb + fit - 1) / fit);
             if (bits == 0) o.passes = 0;
             else if (bits <= 9) { o.passes = 1; o.bits1 = bits; }
-            // Up to two 8448-tuple chunks per partition after ONE 9-bit pass (both relations through the same launches,
-            // ~10 launches in all; the chunked 16-byte-entry kernel joins): a two-pass plan costs ~27 launches, 0.2 ms of
-            // fixed latency that such a join does not have to spare.  [measured] 3M x 3M 0.23 against 0.37 ms, 4M 0.28 / 0.44,
-            // 8M 0.56 / 0.61.
-            else if (nb <= (u64)512 * 2 * join_table_tuples(JK_BKT_BIG) * 15 / 16) { o.passes = 1; o.bits1 = 9; }
+            // Up to two and a half 8448-tuple chunks per partition after ONE 9-bit pass (three launches; the chunked
+            // 16-byte-entry kernel joins): a two-pass plan costs ~27 launches, 0.2 ms of fixed latency that such a join does
+            // not have to spare.  [measured, round 4, wall ms one pass / two] 8.5M 0.43 / 0.50 . 10M 0.51 / 0.54 . 12M 0.61 / 0.59
+            else if (nb <= (u64)512 * 5 * join_table_tuples(JK_BKT_BIG) * 15 / 32) { o.passes = 1; o.bits1 = 9; }
             else {
                 // Two passes.  Up to 16 bits both histograms come from ONE read of the input (k_hist2d_units); a 17- or
                 // 18-bit plan re-reads each relation once more just to count (10.7 instead of 5.4 ms per 10^9-tuple join).
@@ -1205,9 +1204,9 @@ void narrow_note_done(rhj_ctx *ctx, const rhj_opts &plan, bool tried_narrow)   /
 }
 
 // One-pass joins (plans of <= 9 bits: 2 * 10^4 ... 8 * 10^6 build tuples) in THREE launches and no device-to-host copy:
-// k_hist_fused2 (histograms of both relations; its last workgroup makes the partition boundaries, the digit cursors, the
-// join task list and clears the join counters), k_scatter_fused2 (both relations), the bucket join, whose last workgroup
-// publishes the counters to pinned host memory.  Was: unit tables, histogram, three scan launches, scatter, k_make_tasks,
+// k_hist_fused2 (histograms of both relations, the join counters cleared, the next call's control block zeroed),
+// k_scatter_fused2 (both relations; every workgroup derives the partition boundaries itself, a planner workgroup writes them
+// and the join task list meanwhile), the bucket join, which publishes its count to pinned host memory.  Was: unit tables, histogram, three scan launches, scatter, k_make_tasks,
 // join, a 56-byte D2H copy -- 8 dependent launches for 77 us of kernel time at 10^6 x 10^6 (BASELINE config 2).
 bool fused_one_pass_ok(const rhj_ctx *ctx, u64 nR, u64 nS, const rhj_opts &plan)
 {

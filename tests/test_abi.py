@@ -45,8 +45,8 @@ def test_plan_auto():
     p = P(10**6, 10**6)
     assert (p.passes, p.bits1, p.bits2) == (1, 8, 0)    # BASELINE config 2: 1M x 1M, 8-bit, single pass
     p = P(4 * 10**6, 4 * 10**6)
-    assert (p.passes, p.bits1, p.bits2) == (1, 9, 0)    # up to two 8448-tuple chunks per partition: still ONE pass (~10 launches)
-    assert P(8 * 10**6, 10**9).passes == 1 and P(8_200_000, 8_200_000).passes == 2
+    assert (p.passes, p.bits1, p.bits2) == (1, 9, 0)    # up to 2.5 8448-tuple chunks per partition: still ONE pass (three launches)
+    assert P(10 * 10**6, 10**9).passes == 1 and P(10_200_000, 10_200_000).passes == 2
     p = P(2 * 10**8, 2 * 10**8)
     assert p.passes == 2 and p.bits1 + p.bits2 == 16    # avg build partition 3052 <= 15/16 * 4224
     p = P(10**9, 10**9)

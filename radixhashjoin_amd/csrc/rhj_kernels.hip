@@ -1103,12 +1103,16 @@ k_hist_fused2(PassPair a, int shift, int bits, FuseCtl fc, FuseTasks ft)
         for (u32 b = tid; b < nbins; b += PART_THREADS) cnt[b] = 0;
         __syncthreads();
         u64 i = beg + tid;
-        for (; i + 3ull * PART_THREADS < end; i += 4ull * PART_THREADS) {
-            const Tup t0 = x.in[i], t1 = x.in[i + PART_THREADS], t2 = x.in[i + 2 * PART_THREADS], t3 = x.in[i + 3 * PART_THREADS];
-            atomicAdd(&cnt[dig(t0.payload)], 1u);
-            atomicAdd(&cnt[dig(t1.payload)], 1u);
-            atomicAdd(&cnt[dig(t2.payload)], 1u);
-            atomicAdd(&cnt[dig(t3.payload)], 1u);
+        // eight loads in flight per lane: the launch is at most one 512-thread workgroup per CU (the scatter wants few, large
+        // units).  [measured] 8.5 * 10^6 x 8.5 * 10^6, four -> eight: 74 -> 69 us; requesting the next eight before counting the
+        // current ones: no further change -- what is left is the LDS atomics, one wavefront instruction per ~90 cycles per CU,
+        // the same rate k_hist2d_units runs at with 10^9 tuples
+        for (; i + 7ull * PART_THREADS < end; i += 8ull * PART_THREADS) {
+            u64 p[8];
+#pragma unroll
+            for (int q = 0; q < 8; q++) p[q] = x.in[i + (u64)q * PART_THREADS].payload;
+#pragma unroll
+            for (int q = 0; q < 8; q++) atomicAdd(&cnt[dig(p[q])], 1u);
         }
         for (; i < end; i += PART_THREADS) atomicAdd(&cnt[dig(x.in[i].payload)], 1u);
         __syncthreads();

@@ -485,7 +485,13 @@ dev_scan_units(const u64 *__restrict__ seg_start, const u32 *__restrict__ unit_s
     const u32 ge = us + (((g + 1) * per < nu) ? (g + 1) * per : nu);
 
     u64 sum = 0;
-    for (u32 u = gb; u < ge; u++) sum += unit_hist[(u64)u * nbins + d];
+    for (u32 u = gb; u < ge; u += 8) {                  // (eight independent loads per step: see dev_scan1_partial)
+        u32 h[8];
+#pragma unroll
+        for (int q = 0; q < 8; q++) h[q] = u + q < ge ? unit_hist[(u64)(u + q) * nbins + d] : 0u;
+#pragma unroll
+        for (int q = 0; q < 8; q++) sum += h[q];
+    }
     part[g * nbins + d] = sum;
     __syncthreads();
     u64 tot_d = 0, before = 0;
@@ -515,9 +521,13 @@ dev_scan_units(const u64 *__restrict__ seg_start, const u32 *__restrict__ unit_s
         if (s == nseg - 1 && d == nbins - 1) part_start[(u64)nseg * nbins] = n_total;
     }
     u64 run = pstart + before;
-    for (u32 u = gb; u < ge; u++) {
-        unit_base[(u64)u * nbins + d] = run;
-        run += unit_hist[(u64)u * nbins + d];
+    for (u32 u = gb; u < ge; u += 8) {
+        u32 h[8];
+#pragma unroll
+        for (int q = 0; q < 8; q++) h[q] = u + q < ge ? unit_hist[(u64)(u + q) * nbins + d] : 0u;
+#pragma unroll
+        for (int q = 0; q < 8; q++)
+            if (u + q < ge) { unit_base[(u64)(u + q) * nbins + d] = run; run += h[q]; }
     }
 }
 
@@ -556,8 +566,16 @@ dev_scan1_partial(const u32 *__restrict__ unit_start, int bits, const u32 *__res
     u32 ub, ue;
     slice_range(nu, gridDim.x, blockIdx.x, ub, ue);
     for (u32 d = threadIdx.x; d < nbins; d += 1024) {
+        // (eight independent loads per step: these three kernels are nothing but memory latency -- [measured] 20M x 20M, 1024
+        // units x 128 digits: 24 / 28 / 19 us each with one load in flight per thread)
         u64 sum = 0;
-        for (u32 u = ub; u < ue; u++) sum += unit_hist[(u64)u * nbins + d];
+        for (u32 u = ub; u < ue; u += 8) {
+            u32 h[8];
+#pragma unroll
+            for (int q = 0; q < 8; q++) h[q] = u + q < ue ? unit_hist[(u64)(u + q) * nbins + d] : 0u;
+#pragma unroll
+            for (int q = 0; q < 8; q++) sum += h[q];
+        }
         partial[(u64)blockIdx.x * nbins + d] = sum;
     }
 }
@@ -583,7 +601,14 @@ dev_scan1_mid(int bits, u32 nsl, u64 *__restrict__ partial, u64 *__restrict__ pa
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const u32 d = threadIdx.x;
     u64 tot = 0;
-    if (d < nbins) for (u32 k = 0; k < nsl; k++) tot += partial[(u64)k * nbins + d];
+    if (d < nbins)
+        for (u32 k = 0; k < nsl; k += 8) {
+            u64 c[8];
+#pragma unroll
+            for (int q = 0; q < 8; q++) c[q] = k + q < nsl ? partial[(u64)(k + q) * nbins + d] : 0ull;
+#pragma unroll
+            for (int q = 0; q < 8; q++) tot += c[q];
+        }
     u64 inc = tot;
 #pragma unroll
     for (int off = 1; off < 64; off <<= 1) {
@@ -598,10 +623,13 @@ dev_scan1_mid(int bits, u32 nsl, u64 *__restrict__ partial, u64 *__restrict__ pa
         u64 run = pre + inc - tot;
         part_start[d] = run;
         if (d == nbins - 1) part_start[nbins] = n_total;
-        for (u32 k = 0; k < nsl; k++) {
-            const u64 c = partial[(u64)k * nbins + d];
-            partial[(u64)k * nbins + d] = run;
-            run += c;
+        for (u32 k = 0; k < nsl; k += 8) {
+            u64 c[8];
+#pragma unroll
+            for (int q = 0; q < 8; q++) c[q] = k + q < nsl ? partial[(u64)(k + q) * nbins + d] : 0ull;
+#pragma unroll
+            for (int q = 0; q < 8; q++)
+                if (k + q < nsl) { partial[(u64)(k + q) * nbins + d] = run; run += c[q]; }
         }
     }
 }
@@ -627,9 +655,13 @@ dev_scan1_final(const u32 *__restrict__ unit_start, int bits, const u32 *__restr
     slice_range(nu, gridDim.x, blockIdx.x, ub, ue);
     for (u32 d = threadIdx.x; d < nbins; d += 1024) {
         u64 run = partial[(u64)blockIdx.x * nbins + d];
-        for (u32 u = ub; u < ue; u++) {
-            unit_base[(u64)u * nbins + d] = run;
-            run += unit_hist[(u64)u * nbins + d];
+        for (u32 u = ub; u < ue; u += 8) {
+            u32 h[8];
+#pragma unroll
+            for (int q = 0; q < 8; q++) h[q] = u + q < ue ? unit_hist[(u64)(u + q) * nbins + d] : 0u;
+#pragma unroll
+            for (int q = 0; q < 8; q++)
+                if (u + q < ue) { unit_base[(u64)(u + q) * nbins + d] = run; run += h[q]; }
         }
     }
 }

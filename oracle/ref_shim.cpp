@@ -20,6 +20,20 @@
 size_t *singleHistogram(relation &rel, size_t twoInLSB);
 tuple *singlePartition(relation &rel, size_t twoInLSB, const size_t *histogram);
 
+/* JobScheduler::stop with `done` published under queueLock.  The reference's body (JobScheduler.cpp:140-146) sets it and
+ * broadcasts without the lock, so a worker between its `!done` test and pthread_cond_wait (JobScheduler.cpp:29-31) sleeps
+ * through the only wake-up and stop() never returns (oracle/ref_sched_race.cpp); every entry point below stops its scheduler
+ * right after the last job, which is where that window is.  The Makefile compiles JobScheduler.cpp with
+ * -Dstop=ref_stop_racy, so the racy body keeps another symbol and is never called.  Same body as in ref_gpu_seam.cpp. */
+void JobScheduler::stop()
+{
+    pthread_mutex_lock(&queueLock);
+    done = true;
+    pthread_cond_broadcast(&cond_nonempty);
+    pthread_mutex_unlock(&queueLock);
+    for (size_t i = 0; i < num_of_threads; i++) pthread_join(threads[i], nullptr);
+}
+
 static void fill(relation &dst, const void *src, size_t n)
 {
     dst.num_tuples = n;

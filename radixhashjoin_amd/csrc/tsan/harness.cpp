@@ -60,11 +60,11 @@ int main()
     };
     std::vector<std::thread> th;
     // two pipelined callers (K = 4 chunks of S: 4 joins per call), two plain large callers, four small-join callers
-    th.emplace_back(query_thread, 0, 6u << 20, 16u << 20, 3, 4);
-    th.emplace_back(query_thread, 1, 5u << 20, 17u << 20, 2, 4);
-    th.emplace_back(query_thread, 2, 5u << 20, 5u << 20, 3, 1);
-    th.emplace_back(query_thread, 3, 9u << 20, 4u << 20, 2, 1);
-    for (int k = 0; k < 4; k++) th.emplace_back(query_thread, 4 + k, 1500 + 700 * k, 9000 + 3000 * k, 40, 1);
+    th.emplace_back(query_thread, 0, 6u << 20, 16u << 20, 2, 4);
+    th.emplace_back(query_thread, 1, 5u << 20, 17u << 20, 1, 4);
+    th.emplace_back(query_thread, 2, 5u << 20, 5u << 20, 2, 1);
+    th.emplace_back(query_thread, 3, 9u << 20, 4u << 20, 1, 1);
+    for (int k = 0; k < 4; k++) th.emplace_back(query_thread, 4 + k, 1500 + 700 * k, 9000 + 3000 * k, 16, 1);
     // two callers of rhj_join_batch: 40 small joins per call (three launches of <= 16), inputs staged and pages filled by the
     // context's helper threads
     auto batch_thread = [&](int id) {
@@ -74,7 +74,7 @@ int main()
         std::vector<rhj_join_desc> joins;
         for (int j = 0; j < 40; j++) { rel.push_back(relation(900 + 531 * j)); rel.push_back(relation(20000 + 997 * j)); }
         for (int j = 0; j < 40; j++) joins.push_back(rhj_join_desc{rel[2 * j].data(), rel[2 * j].size(), rel[2 * j + 1].data(), rel[2 * j + 1].size()});
-        for (int r = 0; r < 6; r++) {
+        for (int r = 0; r < 3; r++) {
             std::vector<void *> pages(joins.size());
             std::vector<uint64_t> counts(joins.size());
             const int rc = rhj_join_batch(ctx, (uint32_t)joins.size(), joins.data(), pages.data(), counts.data());

@@ -151,10 +151,12 @@ def test_64m_aligned_join_values_closed_form(engine, shift, add):
         engine.remap_keys(dR, n, shift, add)
         engine.remap_keys(dS, n, shift, add)
         engine.sync()
-        t0 = time.perf_counter()
-        assert engine.join_dev(dR, n, dS, n, dO, n) == exp_n
-        t_aligned = time.perf_counter() - t0
-        assert engine.pairs_checksum(dO, n) == exp_c
+        t_aligned = float("inf")
+        for _ in range(3):                                                    # host wall time: the best of three, one hiccup of the box does not decide
+            t0 = time.perf_counter()
+            assert engine.join_dev(dR, n, dS, n, dO, n) == exp_n
+            t_aligned = min(t_aligned, time.perf_counter() - t0)
+            assert engine.pairs_checksum(dO, n) == exp_c
         t = engine.timings()
         nparts = 1 << (t["bits1"] + t["bits2"])
         assert engine.info("last.max_part_R") <= 1.3 * n / nparts + 64
